@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Headline benchmark: gated-GCN forward throughput (edges/s) on MI355X.
+
+One "step" = one pass of the hot path (models/bert_amir5.py:621-640: gate -> gc1 -> gate ->
+gc2 -> gate -> max-pool, 2 GraphConvolution layers, models/gcn.py:30-45) over one batch of
+synthetic dependency graphs already resident in HBM.  Workload = BASELINE.json configs[1]:
+4096 graphs x 32 tokens, avg degree 4 (nnz = 524288 incl. self loops), hidden = 768, fp32.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, every rank owns its own 4096-graph batch (weak scaling; graphs are
+independent, so the data path has no exchange) and the per-shard pooled outputs [B,H] are
+all-gathered over RCCL/xGMI each step -- the path's only collective.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (spec, no sparsity)
+MFMA_F32_PEAK_TF = 157.3     # f32-input MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--graphs", type=int, default=4096, help="graphs per GPU (config 2: 4096)")
+    ap.add_argument("--tokens", type=int, default=32)
+    ap.add_argument("--hidden", type=int, default=768)
+    ap.add_argument("--degree", type=float, default=4.0)
+    ap.add_argument("--precision", default=os.environ.get("GGCN_PRECISION", "bf16x3"), choices=["bf16x3", "fp32"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --graphs per GPU; strong: --graphs in total, sharded (BASELINE configs[2])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-graphs", type=int, default=4096, help="sample size of the CPU baseline")
+    return ap.parse_args()
+
+
+def cpu_baseline(x, adj, g1, g2, w1, b1, w2, b2, n_graphs):
+    """The reference's dense algorithm (oracle/ref_dense.py, bit-equal to the imported reference in
+    the build container) on this host's cores: 1 warm-up + median of 5 forwards."""
+    import torch
+    from oracle import ref_dense
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    n = min(n_graphs, x.shape[0])
+    xs, adjs, g1s, g2s = x[:n], adj[:n].float(), g1[:n], g2[:n]
+    nnz = int((adj[:n] != 0).sum())
+    times = []
+    with torch.no_grad():
+        for i in range(6):
+            t0 = time.perf_counter()
+            ref_dense.gated_block(xs, adjs, g1s, g2s, w1, b1, w2, b2)
+            if i:
+                times.append(time.perf_counter() - t0)
+    t = statistics.median(times)
+    return {"value": nnz / t, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": "%d of the %d graphs (T=%d, H=%d, 2 layers, dense adj, torch-CPU fp32), "
+                      "1 warm-up + median of 5, %.3f s per forward" % (n, x.shape[0], x.shape[1], x.shape[2], t)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import ed_gated_gcn_amd as pkg
+    from ed_gated_gcn_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg.load_library()
+    B_total = args.graphs * world if args.scaling == "weak" else args.graphs
+    B = args.graphs if args.scaling == "weak" else (args.graphs // world)
+    T, H = args.tokens, args.hidden
+
+    # ---- synthetic batch of this rank, resident in HBM before timing --------
+    adj_np = synth.dependency_batch(B, T, args.degree, seed=synth.SEED + rank)
+    rowptr, colidx, _ = synth.csr_from_dense_host(adj_np)
+    nnz = int(rowptr[-1])
+    csr = pkg.BatchedCSR.from_arrays(rowptr, colidx, B, T, dev)
+    gen = torch.Generator().manual_seed(synth.SEED + rank)
+    x_cpu = torch.randn(B, T, H, generator=gen)
+    g1_cpu = torch.sigmoid(torch.randn(B, H, generator=gen))
+    g2_cpu = torch.sigmoid(torch.randn(B, H, generator=gen))
+    w1, b1 = synth.layer_params(H, H, seed=1)
+    w2, b2 = synth.layer_params(H, H, seed=2)
+    x, g1, g2 = x_cpu.to(dev), g1_cpu.to(dev), g2_cpu.to(dev)
+    layers = []
+    for w, b in ((w1, b1), (w2, b2)):
+        m = pkg.GraphConvolution(H, H, opt=None).to(dev)
+        m.precision = args.precision
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(w))
+            m.bias.copy_(torch.from_numpy(b))
+        layers.append(m.eval())
+    gc1, gc2 = layers
+    gathered = torch.empty(world * B, H, device=dev) if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            r = pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, r["out"])
+        return r
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nn = torch.tensor([nnz], device=dev, dtype=torch.int64)
+        dist.all_reduce(nn)
+        nnz_total = int(nn.item())
+    else:
+        nnz_total = nnz
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- per-kernel durations: HIP events on the launch stream (torch's current stream IS the
+    # stream every ggcn_* call is enqueued on), same inputs, right after the timed region ------
+    def time_kernel(fn, n):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize(dev)
+        return statistics.mean(a.elapsed_time(b) for a, b in evs) * 1e-3  # seconds
+
+    n_prof = max(10, min(args.steps, 50))
+    x2d = x.view(B * T, H)
+    with torch.no_grad():
+        hidden = gc1.linear(x2d)
+        t_lin = time_kernel(lambda: gc1.linear(x2d), n_prof)
+    # aggregation alone (layer-1 form: ungated store + two gated pools), through the C ABI
+    from ed_gated_gcn_amd import _capi
+    lib = pkg.load_library()
+    out = torch.empty(B * T, H, device=dev)
+    pa = torch.empty(B, H, device=dev)
+    pb = torch.empty(B, H, device=dev)
+
+    def agg_once():
+        _capi.check(lib.ggcn_aggregate(_capi.ptr(hidden), H, _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), None,
+                                       _capi.ptr(gc1.bias.detach()), B, T, H, None, _capi.ptr(g1), _capi.ptr(g2),
+                                       _capi.ptr(out), H, _capi.ptr(pa), _capi.ptr(pb), _capi.stream_of(dev)),
+                    "ggcn_aggregate")
+    agg_once()
+    t_agg = time_kernel(agg_once, n_prof)
+
+    N = B * T
+    lin_flops = 2.0 * N * H * H                       # algorithmic flops of gcn.py:34 per launch
+    agg_bytes = 2 * 4 * N * H + 4 * (N + 1) + 4 * nnz + 2 * 4 * B * H + 4 * H   # SURVEY 8d minus W
+    fwd_bytes = 2 * synth.algorithmic_bytes_per_layer(B, T, H, nnz)
+    lin_peak = MFMA_BF16_PEAK_TF if args.precision == "bf16x3" else MFMA_F32_PEAK_TF
+    lin_tf = lin_flops / t_lin / 1e12
+    dominant_is_linear = t_lin >= t_agg
+    if dominant_is_linear:
+        roofline = {"kernel": "linear_%s_kernel" % args.precision, "bound": "mfma", "achieved": lin_tf,
+                    "peak": lin_peak, "unit": "TFLOP/s", "frac": lin_tf / lin_peak, "traffic": None,
+                    "avg_launch_us": t_lin * 1e6,
+                    "note": "achieved = algorithmic 2*N*K*F flops / launch; bf16x3 issues 3 bf16 MFMA flops "
+                            "per algorithmic flop, so its ceiling on this peak is 1/3"
+                            if args.precision == "bf16x3" else "exact f32-input MFMA"}
+    else:
+        gbs = agg_bytes / t_agg / 1e9
+        roofline = {"kernel": "aggregate_rows", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_agg * 1e6}
+    kernels = {
+        "linear": {"avg_launch_us": t_lin * 1e6, "algorithmic_tflops": lin_tf, "launches_per_step": 2},
+        "aggregate": {"avg_launch_us": t_agg * 1e6, "algorithmic_GBps": agg_bytes / t_agg / 1e9,
+                      "hbm_frac": agg_bytes / t_agg / 1e9 / HBM_PEAK_GBS, "launches_per_step": 2},
+    }
+
+    result = None
+    if rank == 0:
+        value = nnz_total * args.steps / elapsed
+        result = {
+            "metric": "gated_gcn_forward_edges_per_sec", "value": value, "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f32 (bf16x3 MFMA split, fp32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: %d graphs/GPU x %d tokens, avg degree %g "
+                                   "(nnz %d incl. self loops), hidden %d, 2 gated-GCN layers, fp32 in/out"
+                                   % (B, T, args.degree, nnz, H),
+                       "graphs_total": B_total, "precision": args.precision,
+                       "collective": "all_gather(out[B,H])" if world > 1 else "none"},
+            "edge_layers_per_sec": 2 * value,
+            "forward_algorithmic_bytes": fwd_bytes,
+            "forward_hbm_GBps": fwd_bytes * world / (elapsed / args.steps) / 1e9,
+            "forward_hbm_frac": fwd_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world >= 1:
+            t = torch.from_numpy
+            result["cpu_baseline"] = cpu_baseline(x_cpu, t(adj_np), g1_cpu, g2_cpu, t(w1), t(b1), t(w2), t(b2),
+                                                  args.cpu_graphs)
+            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,23 @@
+"""MI355X-native gated graph convolution: drop-in for the GCN hot path of laiviet/ed-gated-gcn.
+
+The directory carries the reference's (hyphenated) name; import it as
+``ed_gated_gcn_amd`` (the one-file alias at the repository root).
+
+Public surface (mirrors the reference interface for this path):
+
+* ``GraphConvolution``  -- ``models/gcn.py:9-45``: same constructor, parameters,
+  ``state_dict`` and ``forward(text, adj)``.
+* ``gated_gcn_block``   -- ``models/bert_amir5.py:621-640``: gate -> gc1 -> gate ->
+  gc2 -> gate -> max-pool, never materialising the [B,T,H] gates.
+* ``BatchedCSR``        -- many sentence graphs as one block-diagonal CSR.
+
+All compute is in ``libggcn_hip.so`` (hand-written HIP for gfx950, C ABI in
+``include/ggcn.h``).  There is no CPU or PyTorch fallback: without the library or
+a GPU tensor every entry point raises.
+"""
+from ._capi import lib_path, load_library  # noqa: F401
+from .csr import BatchedCSR  # noqa: F401
+from .gcn import GraphConvolution  # noqa: F401
+from .gated_block import gated_gcn_block  # noqa: F401
+
+__all__ = ["GraphConvolution", "gated_gcn_block", "BatchedCSR", "load_library", "lib_path"]

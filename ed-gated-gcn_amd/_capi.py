@@ -1,0 +1,73 @@
+"""ctypes binding of libggcn_hip.so (C ABI: include/ggcn.h).
+
+This is the binding a maintainer of the reference would add next to
+``models/gcn.py``: plain pointers, sizes and a stream handle --
+no torch types cross the boundary.  Missing library => ImportError-like
+RuntimeError, never a silent fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_i32, c_i64, c_vp, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes): exactly the prototypes of include/ggcn.h
+PROTOTYPES = {
+    "ggcn_abi_version": (c_i32, []),
+    "ggcn_last_error": (ctypes.c_char_p, []),
+    "ggcn_csr_workspace_bytes": (c_sz, [c_i64]),
+    "ggcn_csr_from_dense": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp,
+                                    c_i64, c_vp, c_vp]),
+    "ggcn_weight_pack_bytes": (c_sz, [c_i32, c_i32]),
+    "ggcn_weight_pack": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "ggcn_linear": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "ggcn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+                               c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "ggcn_overlap_workspace_bytes": (c_sz, [c_i32]),
+    "ggcn_gate_overlap": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+}
+
+ABI_VERSION = 1
+PREC = {"bf16x3": 0, "fp32": 1}
+
+
+def lib_path():
+    return os.environ.get("GGCN_LIB", os.path.join(_HERE, "libggcn_hip.so"))
+
+
+def load_library():
+    """Load libggcn_hip.so and bind every prototype; raise if it is absent or stale."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "libggcn_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C ed-gated-gcn_amd/csrc` (no CPU fallback exists)" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    if lib.ggcn_abi_version() != ABI_VERSION:
+        raise RuntimeError("libggcn_hip.so ABI %d != binding ABI %d" % (lib.ggcn_abi_version(), ABI_VERSION))
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load_library().ggcn_last_error().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

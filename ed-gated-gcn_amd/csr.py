@@ -1,0 +1,86 @@
+"""Batched (block-diagonal) CSR: many small sentence graphs as ONE sparse matrix.
+
+The reference ships every sentence's adjacency dense, ``float32 [B,ORI_ML,ORI_ML]``
+(``data_utils.py:376,394``), slices it to ``[:, :T, :T]`` (``models/bert_amir5.py:589``)
+and multiplies by it densely (``models/gcn.py:41``).  Here the batch is one CSR over
+N = B*T nodes with GLOBAL node ids, so a single kernel launch covers the whole
+batch.  Padding rows keep their identity self-loop.
+"""
+import torch
+
+from . import _capi
+
+_ADJ_DTYPES = {
+    torch.float32: 0, torch.uint8: 1, torch.bool: 1, torch.int32: 2, torch.int64: 3,
+    torch.float64: 4, torch.float16: 5,
+}
+
+
+class BatchedCSR:
+    """rowptr int32[N+1], colidx int32[cap], vals fp32[cap] or None (binary), on one GPU."""
+
+    __slots__ = ("rowptr", "colidx", "vals", "B", "T", "nnz")
+
+    def __init__(self, rowptr, colidx, vals, B, T, nnz=None):
+        self.rowptr, self.colidx, self.vals = rowptr, colidx, vals
+        self.B, self.T, self.nnz = int(B), int(T), nnz
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    @property
+    def n_nodes(self):
+        return self.B * self.T
+
+    @classmethod
+    def from_dense(cls, adj, binary=False):
+        """Device-side conversion of a dense [B,T,T] adjacency (any real dtype, any strides).
+
+        No host synchronisation: colidx/vals are sized for the worst case B*T*T and
+        ``nnz`` stays unknown (None).  ``binary=True`` promises a 0/1 adjacency and
+        skips the value array (the kernels then use deg+1 as the denominator,
+        ``models/gcn.py:35``)."""
+        if not isinstance(adj, torch.Tensor) or adj.dim() != 3 or adj.shape[1] != adj.shape[2]:
+            raise RuntimeError("adj must be a [B,T,T] tensor, got %r" % (getattr(adj, "shape", None),))
+        if not adj.is_cuda:
+            raise RuntimeError("adj must live on the GPU (no CPU path exists in this package)")
+        if adj.dtype not in _ADJ_DTYPES:
+            raise TypeError("unsupported adjacency dtype %s" % adj.dtype)
+        lib = _capi.load_library()
+        B, T, _ = adj.shape
+        dev = adj.device
+        n = B * T
+        cap = n * T
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        colidx = torch.empty(cap, dtype=torch.int32, device=dev)
+        vals = None if binary else torch.empty(cap, dtype=torch.float32, device=dev)
+        ws = torch.empty(max(1, lib.ggcn_csr_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        sb, sr, sc = adj.stride()
+        with torch.cuda.device(dev):
+            rc = lib.ggcn_csr_from_dense(_capi.ptr(adj), _ADJ_DTYPES[adj.dtype], B, T, sb, sr, sc,
+                                         _capi.ptr(rowptr), _capi.ptr(colidx), _capi.ptr(vals), cap,
+                                         _capi.ptr(ws), _capi.stream_of(dev))
+        _capi.check(rc, "ggcn_csr_from_dense")
+        return cls(rowptr, colidx, vals, B, T)
+
+    @classmethod
+    def from_arrays(cls, rowptr, colidx, B, T, device, vals=None):
+        """Upload a CSR built on the host (numpy int32 arrays, global node ids)."""
+        import numpy as np
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+        if rowptr.shape[0] != B * T + 1:
+            raise RuntimeError("rowptr must have B*T+1 = %d entries, got %d" % (B * T + 1, rowptr.shape[0]))
+        if int(rowptr[-1]) != colidx.shape[0]:
+            raise RuntimeError("rowptr[-1]=%d != len(colidx)=%d" % (int(rowptr[-1]), colidx.shape[0]))
+        if colidx.size and (colidx.min() < 0 or colidx.max() >= B * T):
+            raise RuntimeError("colidx out of range")
+        rows = np.repeat(np.arange(B * T, dtype=np.int64), np.diff(rowptr))
+        if np.any(rows // T != colidx // T):
+            raise RuntimeError("an edge crosses two graphs: the batched CSR must be block-diagonal")
+        v = None
+        if vals is not None:
+            v = torch.from_numpy(np.ascontiguousarray(vals, dtype=np.float32)).to(device)
+        return cls(torch.from_numpy(rowptr).to(device), torch.from_numpy(colidx).to(device), v, B, T,
+                   nnz=int(colidx.shape[0]))

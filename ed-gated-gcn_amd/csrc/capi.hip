@@ -1,0 +1,88 @@
+// extern "C" surface of libggcn_hip.so -- see include/ggcn.h for the contract.
+// Argument checking lives here and in the per-kernel launchers; nothing in this
+// library allocates, frees, copies to the host or synchronises.
+#include "common.h"
+
+#include <cstring>
+
+namespace ggcn {
+
+char *error_buffer()
+{
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace ggcn
+
+using namespace ggcn;
+
+extern "C" {
+
+int ggcn_abi_version(void) { return GGCN_ABI_VERSION; }
+
+const char *ggcn_last_error(void) { return error_buffer(); }
+
+size_t ggcn_csr_workspace_bytes(int64_t n_rows) { return csr_workspace_bytes(n_rows); }
+
+int ggcn_csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t stride_b,
+                        int64_t stride_r, int64_t stride_c, int32_t *rowptr, int32_t *colidx,
+                        float *vals, int64_t capacity, void *workspace, ggcn_stream_t stream)
+{
+    return csr_from_dense(adj, adj_dtype, B, T, stride_b, stride_r, stride_c, rowptr, colidx, vals,
+                          capacity, workspace, as_stream(stream));
+}
+
+size_t ggcn_weight_pack_bytes(int K, int F) { return weight_pack_bytes(K, F); }
+
+int ggcn_weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, ggcn_stream_t stream)
+{
+    return weight_pack(W, ldw, K, F, wpack, as_stream(stream));
+}
+
+int ggcn_linear(const float *X, int64_t ldx, const float *W, int64_t ldw, const void *wpack, float *Y,
+                int64_t ldy, int64_t M, int K, int F, int precision, ggcn_stream_t stream)
+{
+    if (!X || !Y) return fail(GGCN_EINVAL, "ggcn_linear: null pointer");
+    if (M <= 0 || K <= 0 || F <= 0)
+        return fail(GGCN_EINVAL, "ggcn_linear: M=%lld K=%d F=%d must be positive", (long long)M, K, F);
+    if (ldx < K || ldy < F) return fail(GGCN_EINVAL, "ggcn_linear: leading dimension too small");
+    switch (precision) {
+        case GGCN_PREC_BF16X3:
+            return linear_bf16x3(X, ldx, wpack, Y, ldy, M, K, F, as_stream(stream));
+        case GGCN_PREC_FP32:
+            if (!W) return fail(GGCN_EINVAL, "ggcn_linear(fp32): W is NULL");
+            if (ldw < F) return fail(GGCN_EINVAL, "ggcn_linear(fp32): ldw < F");
+            return linear_fp32(X, ldx, W, ldw, Y, ldy, M, K, F, as_stream(stream));
+        default:
+            return fail(GGCN_EINVAL, "ggcn_linear: unknown precision %d", precision);
+    }
+}
+
+int ggcn_aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
+                   const float *vals, const float *bias, int B, int T, int F, const float *store_gate,
+                   const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
+                   float *pool_a, float *pool_b, ggcn_stream_t stream)
+{
+    return aggregate(Hd, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a, pool_gate_b,
+                     out, ldo, pool_a, pool_b, as_stream(stream));
+}
+
+size_t ggcn_overlap_workspace_bytes(int B) { return overlap_workspace_bytes(B); }
+
+int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,
+                      ggcn_stream_t stream)
+{
+    return gate_overlap(x1, y1, B, F, xy, workspace, as_stream(stream));
+}
+
+}  // extern "C"

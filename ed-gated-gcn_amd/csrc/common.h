@@ -1,0 +1,52 @@
+// Shared host-side helpers for libggcn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/ggcn.h"
+
+namespace ggcn {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// Thread-local message behind ggcn_last_error().
+char *error_buffer();
+int fail(int code, const char *fmt, ...);
+
+inline hipStream_t as_stream(ggcn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Every launch goes through this: a refused launch becomes GGCN_ELAUNCH, never a silent no-op.
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GGCN_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return GGCN_OK;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- per-kernel launchers (one per .hip file) --------------------------------
+int csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int64_t sr, int64_t sc,
+                   int32_t *rowptr, int32_t *colidx, float *vals, int64_t capacity, void *workspace,
+                   hipStream_t st);
+size_t csr_workspace_bytes(int64_t n_rows);
+
+int linear_fp32(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y, int64_t ldy,
+                int64_t M, int K, int F, hipStream_t st);
+
+size_t weight_pack_bytes(int K, int F);
+int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, hipStream_t st);
+int linear_bf16x3(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy,
+                  int64_t M, int K, int F, hipStream_t st);
+
+int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
+              const float *vals, const float *bias, int B, int T, int F, const float *store_gate,
+              const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
+              float *pool_a, float *pool_b, hipStream_t st);
+
+size_t overlap_workspace_bytes(int B);
+int gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,
+                 hipStream_t st);
+
+}  // namespace ggcn

@@ -1,0 +1,156 @@
+"""``GraphConvolution`` -- drop-in for ``models/gcn.py:9-45`` running on MI355X.
+
+Same constructor ``(in_features, out_features, opt, bias=True)`` (``gcn.py:14``; ``opt``
+is accepted and, as in the reference, not needed), same parameters ``weight [in,out]``
+and ``bias [out]`` (``gcn.py:18,21``; left uninitialised like the reference --
+``train.py:75-84`` initialises them), same ``forward(text, adj) -> [B,T,out]``
+(``gcn.py:30-45``).  Underneath: dense adjacency -> batched CSR -> MFMA linear ->
+one-wavefront-per-node gated aggregation, all in libggcn_hip.so.
+
+Extras that the classifier block uses (``models/bert_amir5.py:621-640``):
+``forward_gated`` fuses the per-sentence gate and the max-pool over tokens into the
+aggregation pass, taking the gate as ``[B,H]`` instead of a materialised ``[B,T,H]``.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _capi
+from .csr import BatchedCSR
+
+
+def _require_gpu_f32(name, t):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s is on %s: this layer only runs on the GPU (libggcn_hip.so); "
+                           "there is no CPU fallback" % (name, t.device))
+    if t.dtype != torch.float32:
+        # the reference raises a dtype-mismatch RuntimeError for half inputs too
+        raise RuntimeError("%s must be float32, got %s" % (name, t.dtype))
+
+
+class GraphConvolution(nn.Module):
+    """Mean-normalised GCN layer: ``(adj @ (text @ W)) / (rowsum(adj) + 1) + b``."""
+
+    def __init__(self, in_features, out_features, opt=None, bias=True):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = nn.Parameter(torch.empty(in_features, out_features, dtype=torch.float32))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_features, dtype=torch.float32))
+        else:
+            self.register_parameter("bias", None)
+        # arithmetic of the dense linear: "bf16x3" (fast, ~1e-5 abs) or "fp32" (exact fp32 MFMA)
+        self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "bf16x3")
+        self._pack = None
+        self._pack_key = None
+
+    def extra_repr(self):
+        return "in_features=%d, out_features=%d, bias=%s, precision=%s" % (
+            self.in_features, self.out_features, self.bias is not None, self.precision)
+
+    # -- weight image for the bf16x3 linear, rebuilt only when the weight changes ----------
+    def _packed_weight(self, lib, stream):
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._pack is None or self._pack_key != key:
+            nbytes = lib.ggcn_weight_pack_bytes(self.in_features, self.out_features)
+            pack = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            wc = w.detach()
+            if not wc.is_contiguous():
+                wc = wc.contiguous()
+            _capi.check(lib.ggcn_weight_pack(_capi.ptr(wc), self.out_features, self.in_features,
+                                             self.out_features, _capi.ptr(pack), stream), "ggcn_weight_pack")
+            self._pack, self._pack_key = pack, key
+        return self._pack
+
+    def _as_csr(self, adj, text):
+        if isinstance(adj, BatchedCSR):
+            if adj.B != text.shape[0] or adj.T != text.shape[1]:
+                raise RuntimeError("CSR is for B=%d,T=%d but text is %s" % (adj.B, adj.T, tuple(text.shape)))
+            if adj.device != text.device:
+                raise RuntimeError("CSR and text are on different devices")
+            return adj
+        if not isinstance(adj, torch.Tensor):
+            raise TypeError("adj must be a [B,T,T] tensor or a BatchedCSR")
+        if adj.dim() != 3 or adj.shape[0] != text.shape[0] or adj.shape[1] != text.shape[1] \
+                or adj.shape[2] != text.shape[1]:
+            raise RuntimeError("adj %s does not match text %s" % (tuple(adj.shape), tuple(text.shape)))
+        if adj.device != text.device:
+            raise RuntimeError("adj and text are on different devices")
+        return BatchedCSR.from_dense(adj)  # gcn.py:33 accepts any real dtype
+
+    def _check(self, text):
+        _require_gpu_f32("text", text)
+        if text.dim() != 3 or text.shape[2] != self.in_features:
+            raise RuntimeError("text must be [B,T,%d], got %s" % (self.in_features, tuple(text.shape)))
+        if self.weight.device != text.device:
+            raise RuntimeError("weight is on %s but text is on %s" % (self.weight.device, text.device))
+        if torch.is_grad_enabled() and (text.requires_grad or self.weight.requires_grad
+                                        or (self.bias is not None and self.bias.requires_grad)):
+            raise NotImplementedError(
+                "the HIP gated-GCN path is forward/inference only in this build: call it under "
+                "torch.no_grad() (as train.py:223 does for evaluation)")
+        if self.precision not in _capi.PREC:
+            raise RuntimeError("unknown precision %r (use 'bf16x3' or 'fp32')" % (self.precision,))
+
+    def linear(self, x2d):
+        """``hidden = text @ W`` (``gcn.py:34``) on [N,in] -> [N,out]."""
+        lib = _capi.load_library()
+        dev = x2d.device
+        with torch.cuda.device(dev):
+            st = _capi.stream_of(dev)
+            y = torch.empty(x2d.shape[0], self.out_features, dtype=torch.float32, device=dev)
+            w = self.weight.detach()
+            if not w.is_contiguous():
+                w = w.contiguous()
+            pack = self._packed_weight(lib, st) if self.precision == "bf16x3" else None
+            _capi.check(lib.ggcn_linear(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(w), w.stride(0),
+                                        _capi.ptr(pack), _capi.ptr(y), y.stride(0), x2d.shape[0],
+                                        self.in_features, self.out_features, _capi.PREC[self.precision], st),
+                        "ggcn_linear")
+        return y
+
+    def forward_gated(self, text, adj, store_gate=None, pool_gate_a=None, pool_gate_b=None,
+                      want_out=True, want_pool_a=False, want_pool_b=False):
+        """Layer + gate + max-pool in one aggregation pass.
+
+        Returns ``(out [B,T,F] or None, pool_a [B,F] or None, pool_b [B,F] or None)`` with
+        ``out = y * store_gate`` and ``pool_x = max_t (y * pool_gate_x)``, ``y`` being the
+        plain layer output.  Gates are ``[B,F]`` (broadcast over tokens)."""
+        self._check(text)
+        csr = self._as_csr(adj, text)
+        lib = _capi.load_library()
+        B, T, _ = text.shape
+        F = self.out_features
+        dev = text.device
+        x2d = text.reshape(B * T, self.in_features)
+        if x2d.stride(1) != 1:
+            x2d = x2d.contiguous()
+        for name, g in (("store_gate", store_gate), ("pool_gate_a", pool_gate_a), ("pool_gate_b", pool_gate_b)):
+            if g is not None:
+                _require_gpu_f32(name, g)
+                if tuple(g.shape) != (B, F) or not g.is_contiguous():
+                    raise RuntimeError("%s must be a contiguous [B,F]=[%d,%d] tensor, got %s"
+                                       % (name, B, F, tuple(g.shape)))
+        hidden = self.linear(x2d)
+        with torch.cuda.device(dev):
+            st = _capi.stream_of(dev)
+            out = torch.empty(B * T, F, dtype=torch.float32, device=dev) if want_out else None
+            pa = torch.empty(B, F, dtype=torch.float32, device=dev) if want_pool_a else None
+            pb = torch.empty(B, F, dtype=torch.float32, device=dev) if want_pool_b else None
+            bias = None if self.bias is None else self.bias.detach()
+            _capi.check(lib.ggcn_aggregate(_capi.ptr(hidden), hidden.stride(0), _capi.ptr(csr.rowptr),
+                                           _capi.ptr(csr.colidx), _capi.ptr(csr.vals), _capi.ptr(bias),
+                                           B, T, F, _capi.ptr(store_gate), _capi.ptr(pool_gate_a),
+                                           _capi.ptr(pool_gate_b), _capi.ptr(out), F, _capi.ptr(pa),
+                                           _capi.ptr(pb), st), "ggcn_aggregate")
+        return (None if out is None else out.view(B, T, F)), pa, pb
+
+    def forward(self, text, adj):
+        """``models/gcn.py:30-45``; ``adj`` is the reference's dense [B,T,T] (or a BatchedCSR)."""
+        out, _, _ = self.forward_gated(text, adj)
+        return out

@@ -1,0 +1,123 @@
+/* ggcn.h -- C ABI of libggcn_hip.so: the gated graph-convolution hot path of
+ * laiviet/ed-gated-gcn as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * The reference has no native code and no FFI: its boundary for this path is
+ * the Python class GraphConvolution (models/gcn.py:9-45) and the ~20 lines of
+ * BertAmir55.forward that wrap it (models/bert_amir5.py:621-640).  These entry
+ * points are what a binding for that path calls; each one names the reference
+ * lines it replaces.  INTEGRATION.md shows the reference-side binding (a ctypes
+ * stub behind the unchanged nn.Module signature).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc'd or a torch CUDA/HIP tensor's
+ *    data_ptr) unless named host_*; nothing is copied, owned or freed here;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*;
+ *    NULL = the default stream); no call synchronises, allocates or frees, so
+ *    every call may be captured in a hipGraph;
+ *  - return 0 on success, a GGCN_E* code otherwise; ggcn_last_error() gives the
+ *    message of the calling thread's last failure (never NULL);
+ *  - feature matrices are row-major fp32 with an explicit leading dimension in
+ *    ELEMENTS; a batch of B graphs of T nodes is the N = B*T rows b*T .. b*T+T-1;
+ *  - batched CSR: rowptr int32[N+1], colidx int32[nnz] holding GLOBAL node ids
+ *    (block-diagonal: every id of row i lies in i's own graph), vals fp32[nnz]
+ *    or NULL for a binary adjacency (all ones).
+ */
+#ifndef GGCN_H
+#define GGCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGCN_ABI_VERSION 1
+
+typedef void *ggcn_stream_t;
+
+enum ggcn_status {
+    GGCN_OK = 0,
+    GGCN_EINVAL = 1,       /* bad argument (null pointer, negative size, misaligned, ...) */
+    GGCN_ELAUNCH = 2,      /* the HIP runtime refused the launch */
+    GGCN_EUNSUPPORTED = 3  /* valid request this build has no kernel for */
+};
+
+/* dtype of a dense adjacency handed to ggcn_csr_from_dense (models/gcn.py:33
+ * `adj.float()` accepts any real dtype). */
+enum ggcn_adj_dtype {
+    GGCN_ADJ_F32 = 0,
+    GGCN_ADJ_U8 = 1,   /* torch.uint8 and torch.bool */
+    GGCN_ADJ_I32 = 2,
+    GGCN_ADJ_I64 = 3,
+    GGCN_ADJ_F64 = 4,
+    GGCN_ADJ_F16 = 5
+};
+
+/* arithmetic of the dense linear (models/gcn.py:34 `torch.matmul(text, weight)`) */
+enum ggcn_precision {
+    GGCN_PREC_BF16X3 = 0,  /* fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per
+                              product, fp32 accumulate: |err| ~ 2^-16 |x||w| per product */
+    GGCN_PREC_FP32 = 1     /* v_mfma_f32_32x32x2_f32: a k-ordered fp32 FMA chain, exact fp32 */
+};
+
+int ggcn_abi_version(void);
+const char *ggcn_last_error(void);
+
+/* ---- batched CSR from the reference's dense adjacency ---------------------
+ * Replaces models/gcn.py:33 (`adj.float()`) and the structure half of :35/:41.
+ * adj is [B,T,T] of `adj_dtype` with strides in ELEMENTS (the reference passes
+ * a non-contiguous slice, models/bert_amir5.py:589).  Every non-zero adj[b,i,j]
+ * becomes colidx entry b*T+j of row b*T+i (ascending j) with its value in vals
+ * (vals may be NULL when the caller knows adj is 0/1).  `capacity` is the
+ * number of entries colidx/vals can hold (B*T*T always suffices); entries
+ * beyond it are dropped (rowptr still holds the true counts).
+ * `workspace` needs ggcn_csr_workspace_bytes(B*T) bytes. */
+size_t ggcn_csr_workspace_bytes(int64_t n_rows);
+int ggcn_csr_from_dense(const void *adj, int adj_dtype, int B, int T,
+                        int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                        int32_t *rowptr, int32_t *colidx, float *vals, int64_t capacity,
+                        void *workspace, ggcn_stream_t stream);
+
+/* ---- dense linear ----------------------------------------------------------
+ * Replaces models/gcn.py:34: Y[M,F] = X[M,K] . W[K,F]  (W is in x out, gcn.py:18).
+ * GGCN_PREC_BF16X3 needs `wpack`, the bf16 hi/lo image of W made once per weight
+ * update by ggcn_weight_pack (ggcn_weight_pack_bytes(K,F) bytes); GGCN_PREC_FP32
+ * reads W itself and ignores wpack. */
+size_t ggcn_weight_pack_bytes(int K, int F);
+int ggcn_weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, ggcn_stream_t stream);
+int ggcn_linear(const float *X, int64_t ldx, const float *W, int64_t ldw, const void *wpack,
+                float *Y, int64_t ldy, int64_t M, int K, int F, int precision,
+                ggcn_stream_t stream);
+
+/* ---- gated aggregation: one wavefront per destination node ----------------
+ * Replaces models/gcn.py:35-45 and models/bert_amir5.py:627-640 in one pass:
+ *   y[i,:]      = ( sum_e vals[e] * Hd[colidx[e],:] ) / ( sum_e vals[e] + 1 ) + bias
+ *   out[i,:]    = y[i,:] * store_gate[g(i),:]           (store_gate NULL => 1)
+ *   pool_a[g,:] = max over the T rows of graph g of y * pool_gate_a[g,:]
+ *   pool_b[g,:] = likewise with pool_gate_b
+ * Hd [N,F] is the linear's output; gates and pools are [B,F] contiguous.
+ * out may be NULL (pooled outputs only); pool_x NULL disables that pool
+ * (pool_gate_x NULL with pool_x set => gate of ones); bias may be NULL.
+ * N = B*T.  Layer 1 of the block (bert_amir5.py:626-636): store_gate NULL,
+ * pools (gate1,x1) and (gate2,y1).  Layer 2 (:639-640): store_gate = gate2,
+ * pool (gate2,out). */
+int ggcn_aggregate(const float *Hd, int64_t ldh,
+                   const int32_t *rowptr, const int32_t *colidx, const float *vals,
+                   const float *bias, int B, int T, int F,
+                   const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
+                   float *out, int64_t ldo, float *pool_a, float *pool_b,
+                   ggcn_stream_t stream);
+
+/* ---- gate-diversity regulariser --------------------------------------------
+ * Replaces models/bert_amir5.py:638: *xy = mean_b sum_f x1[b,f]*y1[b,f].
+ * x1,y1 [B,F] contiguous, xy one device float.  Deterministic (fixed-order
+ * tree reduction).  workspace: ggcn_overlap_workspace_bytes(B) bytes. */
+size_t ggcn_overlap_workspace_bytes(int B);
+int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy,
+                      void *workspace, ggcn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGCN_H */

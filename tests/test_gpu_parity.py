@@ -1,0 +1,298 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X).  Everything here goes through the
+C ABI of libggcn_hip.so (the Python package only marshals pointers) and is checked against
+
+* the committed golden fixtures the REFERENCE produced (tests/golden, oracle/make_golden.py),
+* the CPU oracle on seeded inputs at sizes it finishes in seconds,
+* size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (BASELINE.json north_star: 1e-4 fp32): the fp32-MFMA linear is an exact fp32 FMA
+chain -> 2e-5 (summation order differs from MKL); the bf16x3 linear -> 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import csr_ref, ref_dense  # noqa: E402  (tests may use the oracle)
+
+TOL = {"fp32": 2e-5, "bf16x3": 1e-4}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import ed_gated_gcn_amd as p
+    p.load_library()  # fails loudly if the HIP library was not built
+    return p
+
+
+def _layer(pkg, dev, w, b, precision):
+    m = pkg.GraphConvolution(w.shape[0], w.shape[1], opt=None, bias=b is not None).to(dev)
+    m.precision = precision
+    with torch.no_grad():
+        m.weight.copy_(torch.from_numpy(w))
+        if b is not None:
+            m.bias.copy_(torch.from_numpy(b))
+    return m.eval()
+
+
+# ---------------------------------------------------------------- CSR builder: bit exact
+@pytest.mark.parametrize("dtype", [torch.float32, torch.uint8, torch.bool, torch.int32, torch.int64,
+                                   torch.float64, torch.float16])
+def test_csr_from_dense_bit_exact(pkg, dev, dtype):
+    from ed_gated_gcn_amd import synth
+    lens = np.random.default_rng(3).integers(1, 32, size=37)
+    adj = synth.dependency_batch(37, 31, 3.0, seed=5, lengths=lens)
+    rowptr, colidx, vals = synth.csr_from_dense_host(adj)
+    # the reference hands over a non-contiguous slice of [B,ORI_ML,ORI_ML] (bert_amir5.py:589)
+    big = torch.zeros(37, 40, 40, dtype=dtype, device=dev)
+    big[:, :31, :31] = torch.from_numpy(adj).to(dev).to(dtype)
+    view = big[:, :31, :31]
+    assert not view.is_contiguous()
+    csr = pkg.BatchedCSR.from_dense(view)
+    torch.cuda.synchronize()
+    got_rowptr = csr.rowptr.cpu().numpy()
+    nnz = int(got_rowptr[-1])
+    assert np.array_equal(got_rowptr, rowptr)
+    assert np.array_equal(csr.colidx[:nnz].cpu().numpy(), colidx)
+    assert np.array_equal(csr.vals[:nnz].cpu().numpy(), vals)
+
+
+def test_csr_weighted_and_large_t(pkg, dev):
+    rng = np.random.default_rng(11)
+    adj = (rng.random((3, 200, 200)) < 0.03).astype(np.float32) * rng.uniform(0.5, 2, (3, 200, 200)).astype(np.float32)
+    adj[:, np.arange(200), np.arange(200)] = 1.0
+    rowptr, colidx, vals = csr_ref.csr_from_dense(adj)
+    csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj).to(dev))
+    nnz = int(rowptr[-1])
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(csr.colidx[:nnz].cpu().numpy(), colidx)
+    assert np.array_equal(csr.vals[:nnz].cpu().numpy(), vals)
+
+
+def test_csr_scan_across_many_tiles(pkg, dev):
+    """N = 5000*7 rows > several 1024-row scan tiles, ragged degrees."""
+    rng = np.random.default_rng(2)
+    adj = (rng.random((5000, 7, 7)) < 0.4).astype(np.uint8)
+    rowptr, colidx, _ = csr_ref.csr_from_dense(adj.astype(np.float32))
+    csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj).to(dev), binary=True)
+    assert csr.vals is None
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(csr.colidx[:int(rowptr[-1])].cpu().numpy(), colidx)
+
+
+# ---------------------------------------------------------------- layer vs reference goldens
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_layer_golden_config1(pkg, dev, golden_dir, precision):
+    """BASELINE.json configs[0]: one 32-token sentence, hidden=300, reference CPU forward."""
+    g = np.load(os.path.join(golden_dir, "gcn_config1.npz"))
+    m = _layer(pkg, dev, g["weight"], g["bias"], precision)
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["text"]).to(dev), torch.from_numpy(g["adj"]).to(dev).float())
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=TOL[precision])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_layer_golden_sweep(pkg, dev, golden_dir, precision):
+    g = np.load(os.path.join(golden_dir, "gcn_sweep.npz"))
+    for i, desc in enumerate(g["cases"]):
+        k = "c%d_" % i
+        bias = g[k + "bias"] if (k + "bias") in g.files else None
+        m = _layer(pkg, dev, g[k + "weight"], bias, precision)
+        adj = torch.from_numpy(g[k + "adj"]).to(dev)          # bool / int64 / float32 / weighted
+        with torch.no_grad():
+            out = m(torch.from_numpy(g[k + "text"]).to(dev), adj)
+        np.testing.assert_allclose(out.cpu().numpy(), g[k + "out"], rtol=0, atol=TOL[precision],
+                                   err_msg="%s (%s)" % (desc, precision))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_gated_block_golden_bertamir55(pkg, dev, golden_dir, precision):
+    g = np.load(os.path.join(golden_dir, "amir55_block.npz"))
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    gc1 = _layer(pkg, dev, g["p_gc1.weight"], g["p_gc1.bias"], precision)
+    gc2 = _layer(pkg, dev, g["p_gc2.weight"], g["p_gc2.bias"], precision)
+    with torch.no_grad():
+        r = pkg.gated_gcn_block(t("lstm_out"), t("adj"), t("gate1"), t("gate2"), gc1, gc2)
+    tol = TOL[precision]
+    np.testing.assert_allclose(r["gcn1"].cpu().numpy(), g["gcn1"], rtol=0, atol=tol)
+    np.testing.assert_allclose(r["x"].cpu().numpy(), g["gate2"][:, None, :] * g["gc2_out"], rtol=0, atol=tol)
+    np.testing.assert_allclose(r["out"].cpu().numpy(), g["out"], rtol=0, atol=tol)
+    assert abs(float(r["xy"]) - float(g["xy"])) <= 1e-4 * max(1.0, abs(float(g["xy"])))
+
+
+# ---------------------------------------------------------------- vs the oracle on seeded inputs
+def _oracle_block(x, adj, g1, g2, w1, b1, w2, b2):
+    t = torch.from_numpy
+    return ref_dense.gated_block(t(x), t(adj), t(g1), t(g2), t(w1), t(b1), t(w2), t(b2))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("B,T,H,padded", [(64, 32, 768, False), (16, 31, 256, True), (3, 100, 200, True),
+                                          (2, 231, 64, True), (1, 1, 8, False)])
+def test_gated_block_vs_oracle(pkg, dev, precision, B, T, H, padded):
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(100 + B + T)
+    lens = rng.integers(max(1, T // 3), T + 1, size=B) if padded else None
+    adj = synth.dependency_batch(B, T, min(4.0, T), seed=7, lengths=lens)
+    x = rng.standard_normal((B, T, H)).astype(np.float32)
+    g1 = (1 / (1 + np.exp(-rng.standard_normal((B, H))))).astype(np.float32)
+    g2 = (1 / (1 + np.exp(-rng.standard_normal((B, H))))).astype(np.float32)
+    w1, b1 = synth.layer_params(H, H, seed=1)
+    w2, b2 = synth.layer_params(H, H, seed=2)
+    ref = _oracle_block(x, adj.astype(np.float32), g1, g2, w1, b1, w2, b2)
+    gc1, gc2 = _layer(pkg, dev, w1, b1, precision), _layer(pkg, dev, w2, b2, precision)
+    td = lambda a: torch.from_numpy(a).to(dev)
+    with torch.no_grad():
+        r = pkg.gated_gcn_block(td(x), td(adj), td(g1), td(g2), gc1, gc2)
+    tol = TOL[precision]
+    for k in ("gcn1", "x1", "y1", "x", "out"):
+        np.testing.assert_allclose(r[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=tol, err_msg=k)
+    assert abs(float(r["xy"]) - float(ref["xy"])) <= 1e-4 * max(1.0, abs(float(ref["xy"])))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("M,K,F", [(256, 768, 768), (1000, 300, 300), (33, 17, 5), (513, 768, 34), (7, 9216, 256)])
+def test_linear_vs_float64(pkg, dev, precision, M, K, F):
+    """gcn.py:34 alone, against a float64 product (odd shapes hit every edge/tail path)."""
+    rng = np.random.default_rng(M + K + F)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w, _ = __import__("ed_gated_gcn_amd").synth.layer_params(K, F, seed=3)
+    m = _layer(pkg, dev, w, None, precision)
+    with torch.no_grad():
+        y = m.linear(torch.from_numpy(x).to(dev)).cpu().numpy()
+    ref = x.astype(np.float64) @ w.astype(np.float64)
+    scale = np.sqrt(K) * np.sqrt(np.mean(x.astype(np.float64) ** 2) * np.mean(w.astype(np.float64) ** 2))
+    bound = {"fp32": 2e-6, "bf16x3": 3e-5}[precision] * max(1.0, scale)
+    assert np.max(np.abs(y - ref)) <= bound
+
+
+def test_unaligned_and_strided_inputs(pkg, dev):
+    """K, F not multiples of 4 -> scalar paths; text given as a non-contiguous view."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(9)
+    B, T, K, F = 5, 9, 13, 7
+    adj = synth.dependency_batch(B, T, 3.0, seed=1)
+    x_big = rng.standard_normal((B, T, K + 3)).astype(np.float32)
+    w, b = synth.layer_params(K, F, seed=4)
+    ref = ref_dense.graph_convolution(torch.from_numpy(x_big[:, :, :K].copy()), torch.from_numpy(adj),
+                                      torch.from_numpy(w), torch.from_numpy(b)).numpy()
+    for precision in ("fp32", "bf16x3"):
+        m = _layer(pkg, dev, w, b, precision)
+        with torch.no_grad():
+            out = m(torch.from_numpy(x_big).to(dev)[:, :, :K], torch.from_numpy(adj).to(dev))
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=TOL[precision])
+
+
+def test_errors_are_loud(pkg, dev):
+    m = pkg.GraphConvolution(8, 8, opt=None).to(dev)
+    x = torch.zeros(2, 4, 8, device=dev)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m(x.half(), torch.zeros(2, 4, 4, device=dev))      # reference: dtype mismatch (F7)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m(x, torch.zeros(2, 5, 5, device=dev))             # shape mismatch
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m(x.cpu(), torch.zeros(2, 4, 4))                   # no CPU path
+    with pytest.raises(NotImplementedError):
+        m(x, torch.zeros(2, 4, 4, device=dev))                 # grad-enabled: forward-only build
+
+
+# ---------------------------------------------------------------- full-size properties (config 2)
+@pytest.fixture(scope="module")
+def config2(pkg, dev):
+    from ed_gated_gcn_amd import synth
+    B, T, H = 4096, 32, 768
+    adj = synth.dependency_batch(B, T, 4.0)
+    rowptr, colidx, _ = synth.csr_from_dense_host(adj)
+    csr = pkg.BatchedCSR.from_arrays(rowptr, colidx, B, T, dev)
+    gen = torch.Generator(device="cpu").manual_seed(synth.SEED)
+    x = torch.randn(B, T, H, generator=gen).to(dev)
+    g1 = torch.sigmoid(torch.randn(B, H, generator=gen)).to(dev)
+    g2 = torch.sigmoid(torch.randn(B, H, generator=gen)).to(dev)
+    w1, b1 = synth.layer_params(H, H, seed=1)
+    w2, b2 = synth.layer_params(H, H, seed=2)
+    return dict(B=B, T=T, H=H, adj=adj, csr=csr, x=x, g1=g1, g2=g2, w1=w1, b1=b1, w2=w2, b2=b2)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_config2_full_size_properties(pkg, dev, config2, precision):
+    c = config2
+    gc1, gc2 = _layer(pkg, dev, c["w1"], c["b1"], precision), _layer(pkg, dev, c["w2"], c["b2"], precision)
+    with torch.no_grad():
+        r = pkg.gated_gcn_block(c["x"], c["csr"], c["g1"], c["g2"], gc1, gc2)
+        # (1) graphs are independent: a 64-graph slice run alone gives the same numbers
+        sl = slice(1000, 1064)
+        from ed_gated_gcn_amd import synth
+        rp, ci, _ = synth.csr_from_dense_host(c["adj"][sl])
+        sub = pkg.BatchedCSR.from_arrays(rp, ci, 64, c["T"], dev)
+        rs = pkg.gated_gcn_block(c["x"][sl].contiguous(), sub, c["g1"][sl].contiguous(),
+                                 c["g2"][sl].contiguous(), gc1, gc2)
+    for k in ("gcn1", "x", "out", "x1", "y1"):
+        assert torch.equal(r[k][sl], rs[k]), k
+    # (2) the slice equals the CPU oracle
+    ref = _oracle_block(c["x"][sl].cpu().numpy(), c["adj"][sl].astype(np.float32), c["g1"][sl].cpu().numpy(),
+                        c["g2"][sl].cpu().numpy(), c["w1"], c["b1"], c["w2"], c["b2"])
+    for k in ("gcn1", "x1", "y1", "x", "out"):
+        np.testing.assert_allclose(rs[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=TOL[precision], err_msg=k)
+    # (3) pooled outputs are the max over tokens of what was stored (bert_amir5.py:635-640)
+    assert torch.equal(r["out"], r["x"].max(dim=1)[0])
+    assert torch.equal(r["x1"], (r["gcn1"] * c["g1"][:, None, :]).max(dim=1)[0])
+    assert torch.equal(r["y1"], (r["gcn1"] * c["g2"][:, None, :]).max(dim=1)[0])
+    # (4) xy regulariser against a float64 evaluation of the same pooled tensors
+    xy64 = (r["x1"].double() * r["y1"].double()).sum(1).mean().item()
+    assert abs(float(r["xy"]) - xy64) <= 1e-5 * abs(xy64)
+    # (5) dense-adjacency entry point == CSR entry point, bit for bit
+    with torch.no_grad():
+        d = gc1(c["x"][:256].contiguous(), torch.from_numpy(c["adj"][:256]).to(dev).float())
+    assert torch.equal(d, r["gcn1"][:256])
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_config2_linearity_and_identity(pkg, dev, config2, precision):
+    """The layer is affine in text: f(a*x + b*y) - bias = a*(f(x)-bias) + b*(f(y)-bias); and with an
+    identity adjacency (padding rows) it is text@W / 2 + bias."""
+    c = config2
+    gc1 = _layer(pkg, dev, c["w1"], c["b1"], precision)
+    bias = torch.from_numpy(c["b1"]).to(dev)
+    B = 512
+    x, y = c["x"][:B].contiguous(), c["x"][B:2 * B].contiguous()
+    from ed_gated_gcn_amd import synth
+    rp, ci, _ = synth.csr_from_dense_host(c["adj"][:B])
+    csr = pkg.BatchedCSR.from_arrays(rp, ci, B, c["T"], dev)
+    with torch.no_grad():
+        fx, fy = gc1(x, csr) - bias, gc1(y, csr) - bias
+        fz = gc1(0.5 * x - 2.0 * y, csr) - bias
+        eye = torch.eye(c["T"], device=dev).expand(B, -1, -1)
+        fi = gc1(x, eye)
+        lin = gc1.linear(x.reshape(B * c["T"], -1)).view(B, c["T"], -1)
+    tol = TOL[precision] * 3
+    assert torch.max(torch.abs(fz - (0.5 * fx - 2.0 * fy))).item() <= tol
+    np.testing.assert_allclose(fi.cpu().numpy(), (lin / 2 + bias).cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_config4_long_document_sample(pkg, dev):
+    """BASELINE.json configs[3] shape (T=512, avg degree 6, hidden=1024) on 4 graphs, fp32."""
+    from ed_gated_gcn_amd import synth
+    B, T, H = 4, 512, 1024
+    adj = synth.dependency_batch(B, T, 6.0, seed=21)
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((B, T, H)).astype(np.float32)
+    w, b = synth.layer_params(H, H, seed=5)
+    ref = ref_dense.graph_convolution(torch.from_numpy(x), torch.from_numpy(adj), torch.from_numpy(w),
+                                      torch.from_numpy(b)).numpy()
+    for precision in ("fp32", "bf16x3"):
+        m = _layer(pkg, dev, w, b, precision)
+        with torch.no_grad():
+            out = m(torch.from_numpy(x).to(dev), torch.from_numpy(adj).to(dev))
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=TOL[precision])

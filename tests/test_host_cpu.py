@@ -1,0 +1,118 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/ggcn.h,
+the host logic (synthetic batcher, CSR validation, module contract) behaves, and the
+product path refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ed_gated_gcn_amd as pkg
+from ed_gated_gcn_amd import _capi, synth
+from ed_gated_gcn_amd.csr import BatchedCSR
+from ed_gated_gcn_amd.gcn import GraphConvolution
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "ggcn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ggcn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared_functions()
+    for must in ("ggcn_csr_from_dense", "ggcn_linear", "ggcn_aggregate", "ggcn_gate_overlap",
+                 "ggcn_weight_pack", "ggcn_abi_version", "ggcn_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(pkg.lib_path())
+    for name in _declared_functions():
+        assert hasattr(lib, name), "libggcn_hip.so does not export %s" % name
+
+
+def test_binding_covers_every_declared_symbol_and_abi_matches():
+    assert sorted(_capi.PROTOTYPES) == _declared_functions()
+    lib = pkg.load_library()
+    assert lib.ggcn_abi_version() == _capi.ABI_VERSION
+    # pure host helpers (no GPU needed)
+    assert lib.ggcn_weight_pack_bytes(768, 768) == 768 * 768 * 2 * 2
+    assert lib.ggcn_weight_pack_bytes(300, 300) == 320 * 320 * 2 * 2
+    assert lib.ggcn_csr_workspace_bytes(131072) == 128 * 4
+    assert lib.ggcn_overlap_workspace_bytes(4096) == 4096 * 4
+
+
+def test_bad_arguments_return_codes_not_crashes():
+    lib = pkg.load_library()
+    rc = lib.ggcn_linear(None, 8, None, 8, None, None, 8, 4, 8, 8, 0, None)
+    assert rc == 1 and b"null" in lib.ggcn_last_error()
+    rc = lib.ggcn_aggregate(None, 8, None, None, None, None, 1, 4, 8, None, None, None, None, 8, None, None, None)
+    assert rc == 1
+    rc = lib.ggcn_csr_from_dense(None, 0, 1, 4, 16, 4, 1, None, None, None, 16, None, None)
+    assert rc == 1
+
+
+def test_module_contract_matches_reference_layer():
+    m = GraphConvolution(6, 10, opt=None)                 # gcn.py:14
+    assert list(m.state_dict().keys()) == ["weight", "bias"]
+    assert tuple(m.weight.shape) == (6, 10) and tuple(m.bias.shape) == (10,)   # gcn.py:18,21
+    assert m.in_features == 6 and m.out_features == 10
+    m2 = GraphConvolution(6, 10, opt=None, bias=False)     # gcn.py:23
+    assert m2.bias is None and list(m2.state_dict().keys()) == ["weight"]
+    # train.py:75-84 walks parameters of children and re-initialises them in place
+    for p in m.parameters():
+        assert p.requires_grad
+    m.load_state_dict({"weight": torch.zeros(6, 10), "bias": torch.ones(10)})
+
+
+def test_no_cpu_fallback():
+    m = GraphConvolution(8, 8, opt=None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 4, 8), torch.zeros(1, 4, 4))
+    with pytest.raises(RuntimeError, match="GPU"):
+        BatchedCSR.from_dense(torch.zeros(1, 4, 4))
+
+
+def test_synthetic_batch_matches_the_contract():
+    adj = synth.dependency_batch(64, 32, 4.0)
+    assert adj.shape == (64, 32, 32) and adj.dtype == np.uint8
+    assert np.all(adj.sum(axis=(1, 2)) == 128)                     # nnz = deg*T exactly
+    assert np.all(adj == adj.transpose(0, 2, 1))                    # symmetric (graph.py:73-74)
+    assert np.all(adj[:, np.arange(32), np.arange(32)] == 1)        # self loops (graph.py:66)
+    rowptr, colidx, vals = synth.csr_from_dense_host(adj)
+    assert rowptr[-1] == 64 * 128 and np.all(vals == 1)
+    # block diagonal with global ids
+    rows = np.repeat(np.arange(64 * 32), np.diff(rowptr))
+    assert np.all(rows // 32 == colidx // 32)
+    # padded variant: padding rows keep exactly their self loop
+    lens = np.array([8, 32, 17, 9])
+    p = synth.dependency_batch(4, 32, 4.0, lengths=lens)
+    for b, n in enumerate(lens):
+        assert np.all(p[b, n:, :].sum(axis=1) == 1) and np.all(p[b, :, n:].sum(axis=0) == 1)
+        # nnz parity: an odd remainder cannot be filled by symmetric edge pairs
+        assert round(4.0 * n) + (32 - n) - p[b].sum() in (0, 1)
+    # deterministic
+    assert np.array_equal(adj, synth.dependency_batch(64, 32, 4.0))
+
+
+def test_algorithmic_bytes_match_survey():
+    # SURVEY 8d / BASELINE.md: config 2, one gate per layer
+    assert synth.algorithmic_bytes_per_layer(4096, 32, 768, 524288) == 822873092
+
+
+def test_from_arrays_validates():
+    adj = synth.dependency_batch(2, 4, 2.0)
+    rowptr, colidx, _ = synth.csr_from_dense_host(adj)
+    with pytest.raises(RuntimeError, match="rowptr"):
+        BatchedCSR.from_arrays(rowptr[:-1], colidx, 2, 4, "cpu")
+    bad = colidx.copy()
+    bad[0] = 5  # row 0 (graph 0) pointing into graph 1
+    with pytest.raises(RuntimeError, match="block-diagonal"):
+        BatchedCSR.from_arrays(rowptr, bad, 2, 4, "cpu")
+    ok = BatchedCSR.from_arrays(rowptr, colidx, 2, 4, "cpu")
+    assert ok.nnz == len(colidx) and ok.n_nodes == 8
