@@ -53,22 +53,33 @@ def cpu_baseline(x, adj, g1, g2, w1, b1, w2, b2, n_graphs):
     the build container) on this host's cores: 1 warm-up + median of 5 forwards."""
     import torch
     from oracle import ref_dense
-    cores = len(os.sched_getaffinity(0))
-    torch.set_num_threads(cores)
+    avail = len(os.sched_getaffinity(0))
     n = min(n_graphs, x.shape[0])
     xs, adjs, g1s, g2s = x[:n], adj[:n].float(), g1[:n], g2[:n]
     nnz = int((adj[:n] != 0).sum())
-    times = []
-    with torch.no_grad():
-        for i in range(6):
-            t0 = time.perf_counter()
+
+    def once():
+        t0 = time.perf_counter()
+        with torch.no_grad():
             ref_dense.gated_block(xs, adjs, g1s, g2s, w1, b1, w2, b2)
-            if i:
-                times.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0
+
+    # torch-CPU slows down when oversubscribed on many-core hosts: probe a few thread counts
+    # (one forward each after a warm-up) and time the fastest -- the baseline gets its best shot.
+    best, cores = None, avail
+    for c in sorted({min(avail, k) for k in (16, 32, 64, avail)}):
+        torch.set_num_threads(c)
+        once()
+        t = once()
+        if best is None or t < best:
+            best, cores = t, c
+    torch.set_num_threads(cores)
+    times = [once() for _ in range(5)]
     t = statistics.median(times)
     return {"value": nnz / t, "unit": "edges/s", "cores": cores, "kind": "port",
             "sample": "%d of the %d graphs (T=%d, H=%d, 2 layers, dense adj, torch-CPU fp32), "
-                      "1 warm-up + median of 5, %.3f s per forward" % (n, x.shape[0], x.shape[1], x.shape[2], t)}
+                      "threads chosen from {16,32,64,all=%d} by a probe, median of 5, %.3f s per forward"
+                      % (n, x.shape[0], x.shape[1], x.shape[2], avail, t)}
 
 
 def main():
