@@ -19,7 +19,10 @@ PROTOTYPES = {
     "ggcn_last_error": (ctypes.c_char_p, []),
     "ggcn_csr_workspace_bytes": (c_sz, [c_i64]),
     "ggcn_csr_from_dense": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp,
-                                    c_i64, c_vp, c_vp]),
+                                    c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "ggcn_csr_rowmask": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "ggcn_layer_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                 c_vp, c_i64, c_vp, c_vp, c_vp]),
     "ggcn_weight_pack_bytes": (c_sz, [c_i32, c_i32]),
     "ggcn_weight_pack": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_linear": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
@@ -31,6 +34,7 @@ PROTOTYPES = {
 
 ABI_VERSION = 1
 PREC = {"bf16x3": 0, "fp32": 1}
+FLAG_WEIGHTED = 1
 
 
 def lib_path():

@@ -17,12 +17,13 @@ _ADJ_DTYPES = {
 
 
 class BatchedCSR:
-    """rowptr int32[N+1], colidx int32[cap], vals fp32[cap] or None (binary), on one GPU."""
+    """rowptr int32[N+1], colidx int32[cap], vals fp32[cap] or None (binary adjacency),
+    rowmask uint32-as-int32[N] or None (T <= 32: bit j of word i = edge i<-j), on one GPU."""
 
-    __slots__ = ("rowptr", "colidx", "vals", "B", "T", "nnz")
+    __slots__ = ("rowptr", "colidx", "vals", "rowmask", "B", "T", "nnz")
 
-    def __init__(self, rowptr, colidx, vals, B, T, nnz=None):
-        self.rowptr, self.colidx, self.vals = rowptr, colidx, vals
+    def __init__(self, rowptr, colidx, vals, B, T, nnz=None, rowmask=None):
+        self.rowptr, self.colidx, self.vals, self.rowmask = rowptr, colidx, vals, rowmask
         self.B, self.T, self.nnz = int(B), int(T), nnz
 
     @property
@@ -34,13 +35,15 @@ class BatchedCSR:
         return self.B * self.T
 
     @classmethod
-    def from_dense(cls, adj, binary=False):
+    def from_dense(cls, adj, binary=None):
         """Device-side conversion of a dense [B,T,T] adjacency (any real dtype, any strides).
 
-        No host synchronisation: colidx/vals are sized for the worst case B*T*T and
-        ``nnz`` stays unknown (None).  ``binary=True`` promises a 0/1 adjacency and
-        skips the value array (the kernels then use deg+1 as the denominator,
-        ``models/gcn.py:35``)."""
+        colidx/vals are sized for the worst case B*T*T and ``nnz`` stays unknown (None).
+        ``binary=True`` promises a 0/1 adjacency (no value array, no host sync; the kernels
+        use deg+1 as the denominator, ``models/gcn.py:35``); ``binary=False`` keeps the
+        values as edge weights; ``binary=None`` (default) lets the device decide: the
+        builder raises a flag when some non-zero differs from 1 and this call reads that one
+        int back (one stream sync -- the reference's forward syncs too, ``bert_amir5.py:580``)."""
         if not isinstance(adj, torch.Tensor) or adj.dim() != 3 or adj.shape[1] != adj.shape[2]:
             raise RuntimeError("adj must be a [B,T,T] tensor, got %r" % (getattr(adj, "shape", None),))
         if not adj.is_cuda:
@@ -54,15 +57,20 @@ class BatchedCSR:
         cap = n * T
         rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         colidx = torch.empty(cap, dtype=torch.int32, device=dev)
-        vals = None if binary else torch.empty(cap, dtype=torch.float32, device=dev)
+        vals = None if binary is True else torch.empty(cap, dtype=torch.float32, device=dev)
+        rowmask = torch.empty(n, dtype=torch.int32, device=dev) if T <= 32 else None
+        flags = torch.empty(1, dtype=torch.int32, device=dev) if binary is None else None
         ws = torch.empty(max(1, lib.ggcn_csr_workspace_bytes(n)), dtype=torch.uint8, device=dev)
         sb, sr, sc = adj.stride()
         with torch.cuda.device(dev):
             rc = lib.ggcn_csr_from_dense(_capi.ptr(adj), _ADJ_DTYPES[adj.dtype], B, T, sb, sr, sc,
                                          _capi.ptr(rowptr), _capi.ptr(colidx), _capi.ptr(vals), cap,
-                                         _capi.ptr(ws), _capi.stream_of(dev))
+                                         _capi.ptr(rowmask), _capi.ptr(flags), _capi.ptr(ws),
+                                         _capi.stream_of(dev))
         _capi.check(rc, "ggcn_csr_from_dense")
-        return cls(rowptr, colidx, vals, B, T)
+        if binary is None and not (int(flags.item()) & _capi.FLAG_WEIGHTED):
+            vals = None
+        return cls(rowptr, colidx, vals, B, T, rowmask=rowmask)
 
     @classmethod
     def from_arrays(cls, rowptr, colidx, B, T, device, vals=None):
@@ -80,7 +88,12 @@ class BatchedCSR:
         if np.any(rows // T != colidx // T):
             raise RuntimeError("an edge crosses two graphs: the batched CSR must be block-diagonal")
         v = None
-        if vals is not None:
+        if vals is not None and not np.all(np.asarray(vals) == 1):
             v = torch.from_numpy(np.ascontiguousarray(vals, dtype=np.float32)).to(device)
+        mask = None
+        if T <= 32:  # 0/1 adjacency words for the fused layer kernel
+            m = np.zeros(B * T, dtype=np.uint32)
+            np.bitwise_or.at(m, rows, (np.uint32(1) << (colidx.astype(np.int64) % T).astype(np.uint32)))
+            mask = torch.from_numpy(m.view(np.int32)).to(device)
         return cls(torch.from_numpy(rowptr).to(device), torch.from_numpy(colidx).to(device), v, B, T,
-                   nnz=int(colidx.shape[0]))
+                   nnz=int(colidx.shape[0]), rowmask=mask)

@@ -36,10 +36,26 @@ size_t ggcn_csr_workspace_bytes(int64_t n_rows) { return csr_workspace_bytes(n_r
 
 int ggcn_csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t stride_b,
                         int64_t stride_r, int64_t stride_c, int32_t *rowptr, int32_t *colidx,
-                        float *vals, int64_t capacity, void *workspace, ggcn_stream_t stream)
+                        float *vals, int64_t capacity, uint32_t *rowmask, int32_t *flags,
+                        void *workspace, ggcn_stream_t stream)
 {
     return csr_from_dense(adj, adj_dtype, B, T, stride_b, stride_r, stride_c, rowptr, colidx, vals,
-                          capacity, workspace, as_stream(stream));
+                          capacity, rowmask, flags, workspace, as_stream(stream));
+}
+
+int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask,
+                     ggcn_stream_t stream)
+{
+    return csr_rowmask(rowptr, colidx, B, T, rowmask, as_stream(stream));
+}
+
+int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask,
+                     const float *bias, int B, int T, int K, int F, const float *store_gate,
+                     const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
+                     float *pool_a, float *pool_b, ggcn_stream_t stream)
+{
+    return layer_fused(X, ldx, wpack, rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out,
+                       ldo, pool_a, pool_b, as_stream(stream));
 }
 
 size_t ggcn_weight_pack_bytes(int K, int F) { return weight_pack_bytes(K, F); }

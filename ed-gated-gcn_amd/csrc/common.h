@@ -28,8 +28,8 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // ---- per-kernel launchers (one per .hip file) --------------------------------
 int csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int64_t sr, int64_t sc,
-                   int32_t *rowptr, int32_t *colidx, float *vals, int64_t capacity, void *workspace,
-                   hipStream_t st);
+                   int32_t *rowptr, int32_t *colidx, float *vals, int64_t capacity, uint32_t *rowmask,
+                   int32_t *flags, void *workspace, hipStream_t st);
 size_t csr_workspace_bytes(int64_t n_rows);
 
 int linear_fp32(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y, int64_t ldy,
@@ -44,6 +44,11 @@ int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t
               const float *vals, const float *bias, int B, int T, int F, const float *store_gate,
               const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
               float *pool_a, float *pool_b, hipStream_t st);
+
+int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask, hipStream_t st);
+int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const float *bias,
+                int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
+                const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b, hipStream_t st);
 
 size_t overlap_workspace_bytes(int B);
 int gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,

@@ -32,7 +32,7 @@ template <typename A, bool FILL>
 __global__ __launch_bounds__(256) void csr_walk_rows(
     const A *__restrict__ adj, int64_t n_rows, int T, int64_t sb, int64_t sr, int64_t sc,
     int32_t *__restrict__ rowptr, int32_t *__restrict__ colidx, float *__restrict__ vals,
-    int64_t capacity)
+    int64_t capacity, uint32_t *__restrict__ rowmask, int32_t *__restrict__ flags)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -42,11 +42,17 @@ __global__ __launch_bounds__(256) void csr_walk_rows(
     const A *r = adj + b * sb + (int64_t)i * sr;
     const int64_t base = FILL ? (int64_t)rowptr[row] : 0;
     int cnt = 0;
+    bool weighted = false;
     for (int j0 = 0; j0 < T; j0 += kWave) {
         const int j = j0 + lane;
         const float v = (j < T) ? load_adj<A>(r + (int64_t)j * sc) : 0.0f;
         const bool nz = (v != 0.0f);
         const unsigned long long m = __ballot(nz);
+        if (FILL) {
+            weighted |= nz && (v != 1.0f);
+            // T <= 32: the ballot IS the row's 0/1 adjacency word (bit j = edge i<-j)
+            if (rowmask && j0 == 0 && lane == 0) rowmask[row] = (uint32_t)m;
+        }
         if (FILL && nz) {
             const int64_t pos = base + cnt + __popcll(m & ((1ull << lane) - 1ull));
             if (pos < capacity) {
@@ -57,6 +63,7 @@ __global__ __launch_bounds__(256) void csr_walk_rows(
         cnt += __popcll(m);
     }
     if (!FILL && lane == 0) rowptr[row] = cnt;
+    if (FILL && flags && __any(weighted) && lane == 0) atomicOr(flags, GGCN_FLAG_WEIGHTED);
 }
 
 // Exclusive scan of one value per thread across a 256-thread workgroup; returns the
@@ -137,7 +144,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_finish(int32_t *__restrict__ 
 
 template <typename A>
 int run(const void *adj, int B, int T, int64_t sb, int64_t sr, int64_t sc, int32_t *rowptr,
-        int32_t *colidx, float *vals, int64_t capacity, void *workspace, hipStream_t st)
+        int32_t *colidx, float *vals, int64_t capacity, uint32_t *rowmask, int32_t *flags,
+        void *workspace, hipStream_t st)
 {
     const int64_t n = (int64_t)B * T;
     const A *a = static_cast<const A *>(adj);
@@ -146,12 +154,13 @@ int run(const void *adj, int B, int T, int64_t sb, int64_t sr, int64_t sc, int32
     int32_t *tile_sum = static_cast<int32_t *>(workspace);
 
     hipLaunchKernelGGL((csr_walk_rows<A, false>), dim3(row_blocks), dim3(256), 0, st, a, n, T, sb, sr,
-                       sc, rowptr, nullptr, nullptr, (int64_t)0);
+                       sc, rowptr, nullptr, nullptr, (int64_t)0, nullptr, nullptr);
+    if (flags) (void)hipMemsetAsync(flags, 0, sizeof(int32_t), st);
     hipLaunchKernelGGL(scan_tile_totals, dim3(tiles), dim3(kScanBlock), 0, st, rowptr, n, tile_sum);
     hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, st, tile_sum, (int)tiles);
     hipLaunchKernelGGL(scan_finish, dim3(tiles), dim3(kScanBlock), 0, st, rowptr, n, tile_sum);
     hipLaunchKernelGGL((csr_walk_rows<A, true>), dim3(row_blocks), dim3(256), 0, st, a, n, T, sb, sr,
-                       sc, rowptr, colidx, vals, capacity);
+                       sc, rowptr, colidx, vals, capacity, rowmask, flags);
     return check_launch("ggcn_csr_from_dense");
 }
 
@@ -165,9 +174,11 @@ size_t csr_workspace_bytes(int64_t n_rows)
 }
 
 int csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int64_t sr, int64_t sc,
-                   int32_t *rowptr, int32_t *colidx, float *vals, int64_t capacity, void *workspace,
-                   hipStream_t st)
+                   int32_t *rowptr, int32_t *colidx, float *vals, int64_t capacity, uint32_t *rowmask,
+                   int32_t *flags, void *workspace, hipStream_t st)
 {
+    if (rowmask && T > 32)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_csr_from_dense: row masks need T <= 32, got T=%d", T);
     if (!adj || !rowptr || !colidx || !workspace)
         return fail(GGCN_EINVAL, "ggcn_csr_from_dense: null pointer");
     if (B <= 0 || T <= 0) return fail(GGCN_EINVAL, "ggcn_csr_from_dense: B=%d T=%d must be positive", B, T);
@@ -176,12 +187,12 @@ int csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int
         return fail(GGCN_EUNSUPPORTED, "ggcn_csr_from_dense: B*T*T=%lld does not fit int32 row pointers",
                     (long long)B * T * T);
     switch (adj_dtype) {
-        case GGCN_ADJ_F32: return run<float>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, workspace, st);
-        case GGCN_ADJ_U8: return run<uint8_t>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, workspace, st);
-        case GGCN_ADJ_I32: return run<int32_t>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, workspace, st);
-        case GGCN_ADJ_I64: return run<int64_t>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, workspace, st);
-        case GGCN_ADJ_F64: return run<double>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, workspace, st);
-        case GGCN_ADJ_F16: return run<__half>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, workspace, st);
+        case GGCN_ADJ_F32: return run<float>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, rowmask, flags, workspace, st);
+        case GGCN_ADJ_U8: return run<uint8_t>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, rowmask, flags, workspace, st);
+        case GGCN_ADJ_I32: return run<int32_t>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, rowmask, flags, workspace, st);
+        case GGCN_ADJ_I64: return run<int64_t>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, rowmask, flags, workspace, st);
+        case GGCN_ADJ_F64: return run<double>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, rowmask, flags, workspace, st);
+        case GGCN_ADJ_F16: return run<__half>(adj, B, T, sb, sr, sc, rowptr, colidx, vals, capacity, rowmask, flags, workspace, st);
         default: return fail(GGCN_EINVAL, "ggcn_csr_from_dense: unknown adj_dtype %d", adj_dtype);
     }
 }

@@ -1,0 +1,227 @@
+// One gated-GCN layer in ONE launch, for graphs of at most 32 nodes with a binary adjacency
+// (the reference's case: ACE sentences, ORI_ML = 31, 0/1 dependency matrices, graph.py:66-74):
+//
+//   hidden = X.W                                   models/gcn.py:34        bf16x3 MFMA main loop
+//   agg    = adj.hidden                            models/gcn.py:41        MFMA on the accumulator
+//   y      = agg / (rowsum(adj)+1) + bias          models/gcn.py:35,41,43  registers
+//   out    = y * store_gate ; pools = max_t(y*g)   models/bert_amir5.py:627-640
+//
+// hidden never goes to HBM: a 32x32 fp32 accumulator tile of v_mfma_f32_32x32x16_bf16 IS
+// "graph g's 32 nodes x 32 features", with the node index in the registers and the feature on
+// the lane -- exactly the B-operand layout of a following MFMA that sums over nodes (cdna
+// guide §3 "An accumulator tile as the next MFMA's operand").  So the neighbour sum is
+//     agg[32 x 32] = ADJ_g[32 x 32] . hidden_g[32 x 32]
+// with ADJ_g the graph's 0/1 matrix as an exact bf16 A operand, expanded in registers from a
+// 32-bit row mask (BatchedCSR.rowmask: bit j of word i = edge i<-j; 4 B per node), and
+// hidden split into THREE bf16 planes (residual 2^-24: the aggregation is fp32-exact).
+// Cost: 6 MFMAs per tile on top of the 144 of the main loop (+4 %), no LDS, no extra pass.
+// k order inside a step: element j of lane half h is node 16s + 8(j>>2) + 4h + (j&3) for both
+// operands (the register->row map of the accumulator), so no data moves between lanes.
+//
+// HBM traffic per layer = X in + out + 4 B/node masks + gates + W: the algorithmic bytes.
+// Graphs with T < 32 occupy a 32-row slot (rows >= T read as zeros, are never stored and never
+// pooled); T > 32 or weighted adjacency -> the unfused path (linear + aggregate.hip).
+#include "bf16x3_core.h"
+
+namespace ggcn {
+namespace {
+
+using namespace bx3;
+
+__device__ __forceinline__ float bf16_bits_to_float(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+// acc -> three bf16 planes as B-operand fragments of the two k-steps
+__device__ __forceinline__ void split3(const f32x16 &acc, bf16x8 (&frag)[3][2])
+{
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = acc[8 * s + j];
+            const __bf16 p0 = (__bf16)v;
+            const float r1 = v - (float)p0;
+            const __bf16 p1 = (__bf16)r1;
+            const float r2 = r1 - (float)p1;
+            frag[0][s][j] = p0;
+            frag[1][s][j] = p1;
+            frag[2][s][j] = (__bf16)r2;
+        }
+}
+
+template <bool AVEC, bool KFULL>
+__global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
+    const float *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
+    const uint32_t *__restrict__ rowmask, const float *__restrict__ bias, int B, int T, int K, int F,
+    const float *__restrict__ store_gate, const float *__restrict__ pool_gate_a,
+    const float *__restrict__ pool_gate_b, float *__restrict__ out, int64_t ldo,
+    float *__restrict__ pool_a, float *__restrict__ pool_b, int g_tiles, int n_wg, int k_steps)
+{
+    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+    int g_tile, n_wgi;
+    if (!tile_of_block(blockIdx.x, g_tiles, n_wg, g_tile, n_wgi)) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wn = tid >> 6;
+    const int g0 = g_tile * 4;  // 4 graph slots of 32 rows per workgroup
+    const int n_tiles_total = (F + NT - 1) / NT;
+    const int nt0 = n_wgi * (BN / NT) + wn * 2;
+
+    // staging row i*32 + r  <->  node r of graph g0+i
+    const int s_r = tid >> 3;
+    const float *arow[4];
+    bool avalid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = g0 + i;
+        avalid[i] = (g < B) && (s_r < T);
+        const int64_t node = avalid[i] ? (int64_t)g * T + s_r : 0;  // clamped, zeroed by the select
+        arow[i] = X + node * ldx;
+    }
+    // this lane's adjacency row (node lane&31) of each of the 4 graphs: in flight under the main loop
+    uint32_t mask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = g0 + i;
+        const bool ok = (g < B) && ((lane & 31) < T);
+        const uint32_t m = rowmask[ok ? (int64_t)g * T + (lane & 31) : 0];
+        mask[i] = ok ? m : 0u;
+    }
+
+    f32x16 acc[4][2];
+    mainloop<AVEC, KFULL, true>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);
+
+    const int c = lane & 31, h = lane >> 5;
+
+    // bias and the gates of the 4 graphs x 2 column tiles: all loads issued together, one latency
+    float vb[2], vsg[4][2], vga[4][2], vgb[4][2];
+    bool col_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gn = (nt0 + j) * NT + c;
+        col_ok[j] = gn < F;
+        const int gnc = col_ok[j] ? gn : 0;
+        vb[j] = bias ? bias[gnc] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t at = (int64_t)(g0 + i < B ? g0 + i : 0) * F + gnc;
+            vsg[i][j] = store_gate ? store_gate[at] : 1.0f;
+            vga[i][j] = pool_gate_a ? pool_gate_a[at] : 1.0f;
+            vgb[i][j] = pool_gate_b ? pool_gate_b[at] : 1.0f;
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = g0 + i;
+        if (g >= B) break;  // workgroup-uniform
+        // ---- adjacency fragments of graph g from this lane's row mask ----
+        bf16x8 afrag[2];
+        const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int bit_lo = 16 * s + 8 * (j >> 2) + (j & 3);  // + 4h
+                afrag[s][j] = ((mask[i] >> (bit_lo + 4 * h)) & 1u) ? one : zero;
+            }
+        // 1 / (rowsum(adj) + 1) of node lane&31 (gcn.py:35); one IEEE division per node
+        const float inv = 1.0f / (float)(__popc(mask[i]) + 1);
+
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (nt0 + j >= n_tiles_total) break;  // wavefront-uniform: column tile past F
+            const int gn = (nt0 + j) * NT + c;
+
+            bf16x8 hfrag[3][2];
+            split3(acc[i][j], hfrag);
+            f32x16 y;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = 0.0f;
+#pragma unroll
+            for (int p = 2; p >= 0; --p)  // smallest plane first
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[s], hfrag[p][s], y, 0, 0, 0);
+
+            float pa = -INFINITY, pb = -INFINITY;
+            float *ob = out ? out + ((int64_t)g * T + 4 * h) * ldo + gn : nullptr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
+                const float inv_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), row0));
+                const float inv_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), row0 + 4));
+                const float v = y[r] * (h ? inv_hi : inv_lo) + vb[j];            // gcn.py:41,43
+                if (row0 + 4 * h < T) {
+                    if (ob && col_ok[j]) ob[(int64_t)row0 * ldo] = v * vsg[i][j];  // bert_amir5.py:626 / :639
+                    pa = fmaxf(pa, v * vga[i][j]);                               // bert_amir5.py:635,640
+                    pb = fmaxf(pb, v * vgb[i][j]);                               // bert_amir5.py:636
+                }
+            }
+            pa = fmaxf(pa, __shfl_xor(pa, 32));
+            pb = fmaxf(pb, __shfl_xor(pb, 32));
+            if (h == 0 && col_ok[j]) {
+                if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
+                if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
+            }
+        }
+    }
+}
+
+// rowmask from a batched CSR (T <= 32): one thread per node
+__global__ __launch_bounds__(256) void rowmask_kernel(const int32_t *__restrict__ rowptr,
+                                                      const int32_t *__restrict__ colidx, int64_t n, int T,
+                                                      uint32_t *__restrict__ rowmask)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t base = i / T * T;
+    uint32_t m = 0;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) m |= 1u << (uint32_t)(colidx[e] - base);
+    rowmask[i] = m;
+}
+
+}  // namespace
+
+int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask, hipStream_t st)
+{
+    if (!rowptr || !colidx || !rowmask) return fail(GGCN_EINVAL, "ggcn_csr_rowmask: null pointer");
+    if (B <= 0 || T <= 0) return fail(GGCN_EINVAL, "ggcn_csr_rowmask: B=%d T=%d must be positive", B, T);
+    if (T > 32) return fail(GGCN_EUNSUPPORTED, "ggcn_csr_rowmask: T=%d > 32 (row masks are 32-bit)", T);
+    const int64_t n = (int64_t)B * T;
+    hipLaunchKernelGGL(rowmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rowptr, colidx, n, T,
+                       rowmask);
+    return check_launch("ggcn_csr_rowmask");
+}
+
+int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const float *bias,
+                int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
+                const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b, hipStream_t st)
+{
+    if (!X || !wpack || !rowmask) return fail(GGCN_EINVAL, "ggcn_layer_fused: null input pointer");
+    if (B <= 0 || T <= 0 || K <= 0 || F <= 0)
+        return fail(GGCN_EINVAL, "ggcn_layer_fused: B=%d T=%d K=%d F=%d must be positive", B, T, K, F);
+    if (T > 32) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: T=%d > 32; use ggcn_linear + ggcn_aggregate", T);
+    if (!out && !pool_a && !pool_b) return fail(GGCN_EINVAL, "ggcn_layer_fused: no output requested");
+    if (ldx < K || (out && ldo < F)) return fail(GGCN_EINVAL, "ggcn_layer_fused: leading dimension too small");
+    if (!aligned16(wpack)) return fail(GGCN_EINVAL, "ggcn_layer_fused: wpack must be 16-byte aligned");
+    const bool avec = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
+    const bool kfull = (K % BK == 0);
+    const int k_steps = round_up(K, BK) / KSTEP;
+    const int64_t g_tiles = ((int64_t)B + 3) / 4;
+    const int n_wg = (F + BN - 1) / BN;
+    const int64_t grid = grid_for(g_tiles, n_wg);
+    if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: batch too large");
+    const char *wp = static_cast<const char *>(wpack);
+#define GGCN_LAUNCH(AV, KF)                                                                                   \
+    hipLaunchKernelGGL((layer_fused_kernel<AV, KF>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
+                       rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, ldo, pool_a,      \
+                       pool_b, (int)g_tiles, n_wg, k_steps)
+    if (avec && kfull) GGCN_LAUNCH(true, true);
+    else if (avec) GGCN_LAUNCH(true, false);
+    else GGCN_LAUNCH(false, false);
+#undef GGCN_LAUNCH
+    return check_launch("ggcn_layer_fused");
+}
+
+}  // namespace ggcn

@@ -10,40 +10,15 @@
 // -> |err| ~ 1e-5 * sqrt(K) * rms|x.w| before the mean-aggregation, far inside the
 // 1e-4 parity gate, at 1/3 of the bf16 rate (833 TFLOP/s ceiling instead of 155).
 //
-// Kernel shape (one workgroup per CU, 512 threads = 8 wavefronts = 2 per SIMD):
-//   * tile 256 (M) x 256 (F), K advanced 32 at a time; wavefronts 2 (M) x 4 (F),
-//     each owning 128 x 64 = 4 x 2 MFMA tiles of 32x32 (128 accumulator VGPRs);
-//   * X is read as fp32 (16 B per lane, one 128-B line per 8 lanes), split in
-//     registers (v_cvt_pk_bf16_f32) and written as two bf16 planes to LDS,
-//     double-buffered: ONE barrier per 32-deep step.  Rows are 64 B; the 16-B chunk
-//     index is XORed with (row>>2)&3 so each ds_read_b128 lane group touches 16
-//     distinct 16-B slots (bank-conflict free; cdna guide §5.5 T2 for 64-B rows);
-//   * W never touches LDS: ggcn_weight_pack stores it ONCE in MFMA B-fragment
-//     order -- [n_tile][k_step][hi|lo][lane][8 x bf16] -- so a wavefront fetches a
-//     fragment with a single coalesced 1 KiB global_load_dwordx4 from L2 (the
-//     2.4 MB image is L2-resident), one k-step ahead of its use;
-//   * the workgroup id is remapped so the F-tiles of one row block run on the
-//     same XCD back to back and share that row block through the XCD's L2.
-//
-// Operand lane maps of v_mfma_f32_32x32x16_bf16 (cdna guide §3): lane l, r = l&31,
-// h = l>>5: A[row r][k = 8h+j], B[k = 8h+j][col r], j = 0..7;
-// C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
-#include "common.h"
+// Kernel shape, operand lane maps and the measured scheduling notes: bf16x3_core.h (the main
+// loop is shared with fused_layer.hip).  This file adds the weight packer and the plain-store
+// epilogue.
+#include "bf16x3_core.h"
 
 namespace ggcn {
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 256, BN = 256, BK = 32;
-constexpr int KSTEP = 16;                 // K per MFMA
-constexpr int NT = 32;                    // columns per MFMA tile
-constexpr int FRAG_BYTES = 64 * 16;       // one B fragment: 64 lanes x 8 bf16
-constexpr int kThreads = 512;
-
-__host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+using namespace bx3;
 
 // ---- W -> fragment-ordered bf16 hi/lo image --------------------------------------------
 // block (n_tile, k_step), 128 threads: thread = (plane, lane)
@@ -66,141 +41,61 @@ __global__ __launch_bounds__(128) void weight_pack_kernel(const float *__restric
     pack[(((int64_t)n_tile * k_steps + k_step) * 2 + plane) * 64 + lane] = v;
 }
 
-// LDS image of one A plane: [256 rows][4 chunks of 16 B], chunk XOR-swizzled by (row>>2)&3
-__device__ __forceinline__ int a_lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-template <bool AVEC>
+template <bool AVEC, bool KFULL>
 __global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
     const float *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
     float *__restrict__ Y, int64_t ldy, int64_t M, int K, int F, int m_tiles, int n_wg, int k_steps)
 {
-    // [buffer][plane][256 x 64 B]
-    __shared__ __attribute__((aligned(16))) char lds[2][2][BM * 64];
-
-    // XCD-aware remap: ids congruent mod 8 share an XCD (observed round-robin dispatch);
-    // inside one XCD's sequence consecutive ids walk the F-tiles of the same row block.
-    const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    const int m_tile = (slot / n_wg) * 8 + xcd;
-    const int n_wgi = slot % n_wg;
-    if (m_tile >= m_tiles) return;  // whole workgroup leaves before any barrier
+    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+    int m_tile, n_wgi;
+    if (!tile_of_block(blockIdx.x, m_tiles, n_wg, m_tile, n_wgi)) return;  // before any barrier
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wn = tid >> 6;
     const int64_t m0 = (int64_t)m_tile * BM;
     const int n_tiles_total = (F + NT - 1) / NT;
     const int nt0 = n_wgi * (BN / NT) + wn * 2;  // this wavefront's first 32-column tile
 
-    // ---- A staging roles: 4 x (row = i*64 + tid/8, k = (tid%8)*4 .. +3) ----
-    const int s_row = tid >> 3;
-    const int s_k4 = (tid & 7) * 4;
-    float4 ra[4];
-    auto load_a = [&](int k0) {
+    // rows past M are clamped to row M-1: a row of A only feeds the same row of Y, never stored
+    const float *arow[4];
+    const bool avalid[4] = {true, true, true, true};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t gm = m0 + i * 64 + s_row;
-            const int gk = k0 + s_k4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gm < M) {
-                const float *p = X + gm * ldx + gk;
-                if (AVEC) {
-                    if (gk < K) v = *reinterpret_cast<const float4 *>(p);
-                } else {
-                    if (gk + 0 < K) v.x = p[0];
-                    if (gk + 1 < K) v.y = p[1];
-                    if (gk + 2 < K) v.z = p[2];
-                    if (gk + 3 < K) v.w = p[3];
-                }
-            }
-            ra[i] = v;
-        }
-    };
-    auto store_a = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 64 + s_row;
-            const int off = a_lds_off(row, s_k4 >> 3) + (s_k4 & 4) * 2;
-            bf16x4 hi, lo;
-            hi[0] = (__bf16)ra[i].x; hi[1] = (__bf16)ra[i].y; hi[2] = (__bf16)ra[i].z; hi[3] = (__bf16)ra[i].w;
-            lo[0] = (__bf16)(ra[i].x - (float)hi[0]);
-            lo[1] = (__bf16)(ra[i].y - (float)hi[1]);
-            lo[2] = (__bf16)(ra[i].z - (float)hi[2]);
-            lo[3] = (__bf16)(ra[i].w - (float)hi[3]);
-            *reinterpret_cast<bf16x4 *>(&lds[buf][0][off]) = hi;
-            *reinterpret_cast<bf16x4 *>(&lds[buf][1][off]) = lo;
-        }
-    };
-
-    // ---- B fragments straight from the packed image (L2) ----
-    const bool nt_live0 = nt0 < n_tiles_total, nt_live1 = nt0 + 1 < n_tiles_total;
-    const char *bbase0 = wpack + ((int64_t)nt0 * k_steps) * 2 * FRAG_BYTES + lane * 16;
-    const char *bbase1 = bbase0 + (int64_t)k_steps * 2 * FRAG_BYTES;
-    auto load_b = [&](int ks, bf16x8 (&b)[2][2]) {  // [col tile][plane]
-        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int64_t o = (int64_t)ks * 2 * FRAG_BYTES;
-        const bool k_live = ks < k_steps;
-        b[0][0] = (nt_live0 && k_live) ? *reinterpret_cast<const bf16x8 *>(bbase0 + o) : z;
-        b[0][1] = (nt_live0 && k_live) ? *reinterpret_cast<const bf16x8 *>(bbase0 + o + FRAG_BYTES) : z;
-        b[1][0] = (nt_live1 && k_live) ? *reinterpret_cast<const bf16x8 *>(bbase1 + o) : z;
-        b[1][1] = (nt_live1 && k_live) ? *reinterpret_cast<const bf16x8 *>(bbase1 + o + FRAG_BYTES) : z;
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int f_row = wm * 128 + (lane & 31);
-    const int f_half = lane >> 5;
-
-    auto mma_step = [&](int buf, int s, const bf16x8 (&b)[2][2]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = a_lds_off(f_row + i * 32, s * 2 + f_half);
-            const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(&lds[buf][0][off]);
-            const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(&lds[buf][1][off]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][0], acc[i][j], 0, 0, 0);
-            }
-        }
-    };
-
-    bf16x8 b0[2][2], b1[2][2];
-    const int stages = (K + BK - 1) / BK;
-    load_a(0);
-    load_b(0, b0);
-    for (int st = 0; st < stages; ++st) {
-        const int buf = st & 1;
-        store_a(buf);
-        __syncthreads();  // the only barrier of the stage (double-buffered LDS)
-        if (st + 1 < stages) load_a((st + 1) * BK);
-        load_b(st * 2 + 1, b1);
-        mma_step(buf, 0, b0);
-        load_b(st * 2 + 2, b0);
-        mma_step(buf, 1, b1);
+    for (int i = 0; i < 4; ++i) {
+        int64_t gm = m0 + i * 32 + (tid >> 3);
+        gm = gm < M ? gm : M - 1;
+        arow[i] = X + gm * ldx;
     }
+    f32x16 acc[4][2];
+    mainloop<AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);
 
-    // ---- epilogue: plain store (fused variants live in fused_layer.hip) ----
+#ifndef GGCN_LAB_NO_STORE
+    const bool full_rows = m0 + BM <= M;  // workgroup-uniform: the row guard only exists in the last tile
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int gn = (nt0 + j) * NT + (lane & 31);
         if (gn >= F) continue;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const int64_t gmb = m0 + i * 32 + 4 * (lane >> 5);
+            float *yb = Y + gmb * ldy + gn;
+            if (full_rows) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t gm = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (gm < M) Y[gm * ldy + gn] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) yb[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (gmb + (r & 3) + 8 * (r >> 2) < M) yb[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r];
             }
+        }
     }
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    if (M < 0) Y[0] = 0.f;
+#endif
 }
 
 }  // namespace
@@ -208,9 +103,9 @@ __global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
 size_t weight_pack_bytes(int K, int F)
 {
     if (K <= 0 || F <= 0) return 0;
-    const size_t k_steps = (size_t)round_up(K, BK) / KSTEP;  // padded to whole 32-deep stages
-    const size_t n_tiles = (size_t)round_up(F, NT) / NT;
-    return n_tiles * k_steps * 2 * FRAG_BYTES;
+    const size_t k_steps = (size_t)bx3::round_up(K, bx3::BK) / bx3::KSTEP;  // whole 32-deep stages
+    const size_t n_tiles = (size_t)bx3::round_up(F, bx3::NT) / bx3::NT;
+    return n_tiles * k_steps * 2 * bx3::FRAG_BYTES;
 }
 
 int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, hipStream_t st)
@@ -232,19 +127,20 @@ int linear_bf16x3(const float *X, int64_t ldx, const void *wpack, float *Y, int6
     if (!wpack) return fail(GGCN_EINVAL, "ggcn_linear(bf16x3): wpack is NULL (call ggcn_weight_pack first)");
     if (!aligned16(wpack)) return fail(GGCN_EINVAL, "ggcn_linear(bf16x3): wpack must be 16-byte aligned");
     const bool avec = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
+    const bool kfull = (K % BK == 0);
     const int k_steps = round_up(K, BK) / KSTEP;
     const int64_t m_tiles = (M + BM - 1) / BM;
     const int n_wg = (F + BN - 1) / BN;
-    const int64_t grid = (m_tiles + 7) / 8 * 8 * n_wg;
-    if (grid > (int64_t)INT32_MAX || m_tiles > (int64_t)INT32_MAX)
-        return fail(GGCN_EUNSUPPORTED, "ggcn_linear(bf16x3): M too large");
+    const int64_t grid = grid_for(m_tiles, n_wg);
+    if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_linear(bf16x3): M too large");
     const char *wp = static_cast<const char *>(wpack);
-    if (avec)
-        hipLaunchKernelGGL((linear_bf16x3_kernel<true>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp,
-                           Y, ldy, M, K, F, (int)m_tiles, n_wg, k_steps);
-    else
-        hipLaunchKernelGGL((linear_bf16x3_kernel<false>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp,
-                           Y, ldy, M, K, F, (int)m_tiles, n_wg, k_steps);
+#define GGCN_LAUNCH(AV, KF)                                                                                 \
+    hipLaunchKernelGGL((linear_bf16x3_kernel<AV, KF>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, \
+                       wp, Y, ldy, M, K, F, (int)m_tiles, n_wg, k_steps)
+    if (avec && kfull) GGCN_LAUNCH(true, true);
+    else if (avec) GGCN_LAUNCH(true, false);
+    else GGCN_LAUNCH(false, false);
+#undef GGCN_LAUNCH
     return check_launch("ggcn_linear(bf16x3)");
 }
 

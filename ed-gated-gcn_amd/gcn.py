@@ -45,6 +45,8 @@ class GraphConvolution(nn.Module):
             self.register_parameter("bias", None)
         # arithmetic of the dense linear: "bf16x3" (fast, ~1e-5 abs) or "fp32" (exact fp32 MFMA)
         self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "bf16x3")
+        # one-launch layer (fused_layer.hip) when the batch allows it: T <= 32, binary adjacency, bf16x3
+        self.fused = bool(getattr(opt, "ggcn_fused", True)) and os.environ.get("GGCN_FUSED", "1") != "0"
         self._pack = None
         self._pack_key = None
 
@@ -136,13 +138,23 @@ class GraphConvolution(nn.Module):
                 if tuple(g.shape) != (B, F) or not g.is_contiguous():
                     raise RuntimeError("%s must be a contiguous [B,F]=[%d,%d] tensor, got %s"
                                        % (name, B, F, tuple(g.shape)))
-        hidden = self.linear(x2d)
+        use_fused = (self.fused and self.precision == "bf16x3" and csr.rowmask is not None
+                     and csr.vals is None)
+        hidden = None if use_fused else self.linear(x2d)
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
             out = torch.empty(B * T, F, dtype=torch.float32, device=dev) if want_out else None
             pa = torch.empty(B, F, dtype=torch.float32, device=dev) if want_pool_a else None
             pb = torch.empty(B, F, dtype=torch.float32, device=dev) if want_pool_b else None
             bias = None if self.bias is None else self.bias.detach()
+            if use_fused:
+                pack = self._packed_weight(lib, st)
+                _capi.check(lib.ggcn_layer_fused(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack),
+                                                 _capi.ptr(csr.rowmask), _capi.ptr(bias), B, T,
+                                                 self.in_features, F, _capi.ptr(store_gate),
+                                                 _capi.ptr(pool_gate_a), _capi.ptr(pool_gate_b), _capi.ptr(out),
+                                                 F, _capi.ptr(pa), _capi.ptr(pb), st), "ggcn_layer_fused")
+                return (None if out is None else out.view(B, T, F)), pa, pb
             _capi.check(lib.ggcn_aggregate(_capi.ptr(hidden), hidden.stride(0), _capi.ptr(csr.rowptr),
                                            _capi.ptr(csr.colidx), _capi.ptr(csr.vals), _capi.ptr(bias),
                                            B, T, F, _capi.ptr(store_gate), _capi.ptr(pool_gate_a),

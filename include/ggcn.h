@@ -20,7 +20,10 @@
  *    ELEMENTS; a batch of B graphs of T nodes is the N = B*T rows b*T .. b*T+T-1;
  *  - batched CSR: rowptr int32[N+1], colidx int32[nnz] holding GLOBAL node ids
  *    (block-diagonal: every id of row i lies in i's own graph), vals fp32[nnz]
- *    or NULL for a binary adjacency (all ones).
+ *    or NULL for a binary adjacency (all ones);
+ *  - row masks (graphs of at most 32 nodes): rowmask uint32[N], bit j of word b*T+i set
+ *    iff adj[b,i,j] != 0 -- the 0/1 adjacency at one bit per entry, consumed by
+ *    ggcn_layer_fused.
  */
 #ifndef GGCN_H
 #define GGCN_H
@@ -54,6 +57,11 @@ enum ggcn_adj_dtype {
     GGCN_ADJ_F16 = 5
 };
 
+/* bits of the `flags` word written by ggcn_csr_from_dense */
+enum ggcn_csr_flags {
+    GGCN_FLAG_WEIGHTED = 1 /* some non-zero entry differs from 1: the adjacency carries edge weights */
+};
+
 /* arithmetic of the dense linear (models/gcn.py:34 `torch.matmul(text, weight)`) */
 enum ggcn_precision {
     GGCN_PREC_BF16X3 = 0,  /* fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per
@@ -72,12 +80,19 @@ const char *ggcn_last_error(void);
  * (vals may be NULL when the caller knows adj is 0/1).  `capacity` is the
  * number of entries colidx/vals can hold (B*T*T always suffices); entries
  * beyond it are dropped (rowptr still holds the true counts).
+ * rowmask (NULL or uint32[B*T], needs T <= 32) receives the row masks; flags (NULL or
+ * one device int32) receives ggcn_csr_flags.
  * `workspace` needs ggcn_csr_workspace_bytes(B*T) bytes. */
 size_t ggcn_csr_workspace_bytes(int64_t n_rows);
 int ggcn_csr_from_dense(const void *adj, int adj_dtype, int B, int T,
                         int64_t stride_b, int64_t stride_r, int64_t stride_c,
                         int32_t *rowptr, int32_t *colidx, float *vals, int64_t capacity,
+                        uint32_t *rowmask, int32_t *flags,
                         void *workspace, ggcn_stream_t stream);
+
+/* Row masks from an existing batched CSR (T <= 32). */
+int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
+                     uint32_t *rowmask, ggcn_stream_t stream);
 
 /* ---- dense linear ----------------------------------------------------------
  * Replaces models/gcn.py:34: Y[M,F] = X[M,K] . W[K,F]  (W is in x out, gcn.py:18).
@@ -108,6 +123,18 @@ int ggcn_aggregate(const float *Hd, int64_t ldh,
                    const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
                    float *out, int64_t ldo, float *pool_a, float *pool_b,
                    ggcn_stream_t stream);
+
+/* ---- one whole gated layer in one launch (graphs of <= 32 nodes, binary adjacency) ----
+ * Replaces models/gcn.py:34-45 + models/bert_amir5.py:627-640 without materialising
+ * `hidden`: the bf16x3 linear's accumulator tile (one graph x 32 features) is multiplied by
+ * the graph's 0/1 adjacency with a second MFMA, then divided, biased, gated, pooled and
+ * stored.  Same outputs and argument meaning as ggcn_linear(GGCN_PREC_BF16X3) followed by
+ * ggcn_aggregate; X is [B*T, K], wpack from ggcn_weight_pack(K, F), rowmask uint32[B*T]. */
+int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask,
+                     const float *bias, int B, int T, int K, int F,
+                     const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
+                     float *out, int64_t ldo, float *pool_a, float *pool_b,
+                     ggcn_stream_t stream);
 
 /* ---- gate-diversity regulariser --------------------------------------------
  * Replaces models/bert_amir5.py:638: *xy = mean_b sum_f x1[b,f]*y1[b,f].

@@ -53,7 +53,11 @@ def test_bad_arguments_return_codes_not_crashes():
     assert rc == 1 and b"null" in lib.ggcn_last_error()
     rc = lib.ggcn_aggregate(None, 8, None, None, None, None, 1, 4, 8, None, None, None, None, 8, None, None, None)
     assert rc == 1
-    rc = lib.ggcn_csr_from_dense(None, 0, 1, 4, 16, 4, 1, None, None, None, 16, None, None)
+    rc = lib.ggcn_csr_from_dense(None, 0, 1, 4, 16, 4, 1, None, None, None, 16, None, None, None, None)
+    assert rc == 1
+    rc = lib.ggcn_layer_fused(None, 8, None, None, None, 1, 4, 8, 8, None, None, None, None, 8, None, None, None)
+    assert rc == 1
+    rc = lib.ggcn_csr_rowmask(None, None, 1, 4, None, None)
     assert rc == 1
 
 
@@ -116,3 +120,10 @@ def test_from_arrays_validates():
         BatchedCSR.from_arrays(rowptr, bad, 2, 4, "cpu")
     ok = BatchedCSR.from_arrays(rowptr, colidx, 2, 4, "cpu")
     assert ok.nnz == len(colidx) and ok.n_nodes == 8
+    # row masks: bit j of word b*T+i <=> adj[b,i,j] != 0
+    want = (adj.reshape(8, 4).astype(np.uint32) << np.arange(4, dtype=np.uint32)).sum(axis=1)
+    assert np.array_equal(ok.rowmask.numpy().view(np.uint32), want)
+    assert ok.vals is None
+    big = synth.dependency_batch(1, 40, 3.0)
+    rp, ci, _ = synth.csr_from_dense_host(big)
+    assert BatchedCSR.from_arrays(rp, ci, 1, 40, "cpu").rowmask is None   # T > 32: no masks

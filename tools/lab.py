@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Kernel lab: build variants of libggcn_hip.so with extra -D flags and time one entry point of
+each, interleaved in ONE process (cdna guide §5.4 rule 24).  Development tool, not product code.
+
+  python tools/lab.py build  name1:-DFLAG_A name2:"-DFLAG_B -DFLAG_C" ...   (CPU box: cross-compiles)
+  python tools/lab.py time linear|aggregate|block [names...]                 (GPU box)
+"""
+import ctypes
+import os
+import statistics
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "ed-gated-gcn_amd", "csrc")
+LAB = os.path.join(ROOT, "tools", "_lab")
+
+
+def build(specs):
+    os.makedirs(LAB, exist_ok=True)
+    srcs = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    procs = []
+    for spec in specs:
+        name, _, flags = spec.partition(":")
+        out = os.path.join(LAB, "libggcn_%s.so" % name)
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-o", out] + flags.split() + [os.path.join(CSRC, s) for s in srcs]
+        procs.append((name, subprocess.Popen(cmd)))
+    for name, p in procs:
+        if p.wait():
+            raise SystemExit("build of %s failed" % name)
+        print("built", name)
+
+
+def time_variants(what, names):
+    import torch
+    import ed_gated_gcn_amd as pkg
+    from ed_gated_gcn_amd import _capi, synth
+    dev = torch.device("cuda:0")
+    B, T, H = 4096, 32, 768
+    N = B * T
+    adj = synth.dependency_batch(B, T, 4.0)
+    rowptr, colidx, _ = synth.csr_from_dense_host(adj)
+    csr = pkg.BatchedCSR.from_arrays(rowptr, colidx, B, T, dev)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(N, H, generator=gen).to(dev)
+    g1 = torch.sigmoid(torch.randn(B, H, generator=gen)).to(dev)
+    g2 = torch.sigmoid(torch.randn(B, H, generator=gen)).to(dev)
+    w, b = synth.layer_params(H, H, seed=1)
+    w, b = torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)
+    y = torch.empty(N, H, device=dev)
+    out = torch.empty(N, H, device=dev)
+    pa, pb = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+    if not names:
+        names = sorted(f[len("libggcn_"):-3] for f in os.listdir(LAB) if f.endswith(".so"))
+    libs = {}
+    for n in names:
+        path = os.path.join(LAB, "libggcn_%s.so" % n) if n != "main" else pkg.lib_path()
+        lib = ctypes.CDLL(path)
+        for fn, (res, args) in _capi.PROTOTYPES.items():
+            getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
+        pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H), dtype=torch.uint8, device=dev)
+        assert lib.ggcn_weight_pack(_capi.ptr(w), H, H, H, _capi.ptr(pack), None) == 0
+        libs[n] = (lib, pack)
+    st = _capi.stream_of(dev)
+    p = _capi.ptr
+
+    def run(n):
+        lib, pack = libs[n]
+        if what == "linear":
+            rc = lib.ggcn_linear(p(x), H, p(w), H, p(pack), p(y), H, N, H, H, 0, st)
+        elif what == "linear_fp32":
+            rc = lib.ggcn_linear(p(x), H, p(w), H, None, p(y), H, N, H, H, 1, st)
+        elif what == "aggregate":
+            rc = lib.ggcn_aggregate(p(x), H, p(csr.rowptr), p(csr.colidx), None, p(b), B, T, H, None, p(g1), p(g2),
+                                    p(out), H, p(pa), p(pb), st)
+        elif what == "fused":
+            rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
+                                      p(out), H, p(pa), p(pb), st)
+        else:
+            raise SystemExit("unknown target " + what)
+        assert rc == 0, lib.ggcn_last_error()
+
+    ref = None
+    for n in names:
+        run(n)
+        torch.cuda.synchronize()
+        res = (y if what.startswith("linear") else out).clone()
+        if ref is None:
+            ref = res
+        print("%-24s max|diff vs %s| = %.3g" % (n, names[0], float((res - ref).abs().max())))
+    times = {n: [] for n in names}
+    for rnd in range(12):
+        for n in names:
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                run(n)
+            e.record()
+            torch.cuda.synchronize()
+            if rnd >= 2:
+                times[n].append(a.elapsed_time(e) / 5 * 1e3)
+    for n in names:
+        print("%-24s median %8.1f us   min %8.1f us" % (n, statistics.median(times[n]), min(times[n])))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build(sys.argv[2:])
+    else:
+        time_variants(sys.argv[2], sys.argv[3:])
