@@ -11,8 +11,8 @@
 // workgroups, so one's split/LDS-write/barrier phase overlaps the other's MFMAs).  Each
 // wavefront owns 128 x 64 = 4 x 2 MFMA tiles of 32x32 (128 accumulator VGPRs).
 //   * A: 16-B global loads (one 128-B line per 8 lanes), split in registers
-//     (v_cvt_pk_bf16_f32), two bf16 planes in LDS, double-buffered: ONE barrier per 32-deep
-//     stage.  LDS rows are 64 B; the 16-B chunk index is XORed with (row>>2)&3 so every
+//     (v_cvt_pk_bf16_f32) BETWEEN the MFMAs of the previous stage, two bf16 planes in LDS,
+//     double-buffered: ONE barrier per 32-deep stage.  LDS rows are 64 B; the 16-B chunk index is XORed with (row>>2)&3 so every
 //     ds_read_b128 lane group touches 16 distinct 16-B slots (measured: 0 bank conflicts).
 //   * W never touches LDS: ggcn_weight_pack stores it once in MFMA B-fragment order
 //     [n_tile][k_step][hi|lo][lane][8 x bf16]; a fragment is one coalesced 1 KiB load from L2,
@@ -27,6 +27,8 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 namespace ggcn {
 namespace bx3 {
 
@@ -34,17 +36,33 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 256, BK = 32;
+#ifndef GGCN_BK
+#define GGCN_BK 32
+#endif
+constexpr int BM = 128, BN = 256, BK = GGCN_BK;  // BK 32 or 64
 constexpr int KSTEP = 16;             // K per MFMA
+constexpr int KS = BK / KSTEP;        // MFMA k-steps per stage
+constexpr int TPR = BK / 4;           // threads covering one row of a stage (float4 each)
+constexpr int RPP = 256 / TPR;        // rows per staging pass of the workgroup
+constexpr int NP = BM / RPP;          // staging passes (= float4 registers per thread)
+constexpr int ROWB = BK * 2;          // bytes per LDS row of one plane
 constexpr int NT = 32;                // columns per MFMA tile
 constexpr int FRAG_BYTES = 64 * 16;   // one B fragment: 64 lanes x 8 bf16
 constexpr int kThreads = 256;
-constexpr int kLdsBytes = 2 * 2 * BM * 64;  // [buffer][plane][128 rows x 64 B] = 32 KiB
+constexpr int kLdsBytes = 2 * 2 * BM * ROWB;  // [buffer][plane][128 rows x ROWB]: 32 KiB (BK 32) / 64 KiB
 
 __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// LDS image of one A plane: [128 rows][4 chunks of 16 B], chunk XOR-swizzled by (row>>2)&3
-__device__ __forceinline__ int a_lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// LDS image of one A plane: [128 rows][ROWB/16 chunks of 16 B].  The chunk index is XORed so
+// that the 16 rows of a ds_read_b128 lane group land on 16 distinct 16-B slots of the 256-B
+// bank row: 64-B rows (4 rows per bank row): chunk ^ (row>>2)&3; 128-B rows: chunk ^ (row>>1)&7.
+__device__ __forceinline__ int a_lds_off(int row, int chunk)
+{
+    if constexpr (BK == 32) return row * ROWB + ((chunk ^ ((row >> 2) & 3)) << 4);
+    else return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+// staging row of pass p for this thread
+__device__ __forceinline__ int stage_row(int p) { return p * RPP + (int)threadIdx.x / TPR; }
 
 // XCD-aware remap of a 1-D grid: ids congruent mod 8 share an XCD (observed round-robin
 // dispatch; speed only, never correctness); inside one XCD's sequence consecutive ids walk the
@@ -62,20 +80,18 @@ inline int64_t grid_for(int64_t m_tiles, int n_wg) { return (m_tiles + 7) / 8 * 
 // the row is padding and must read as zeros.  AVEC: 16-B loads allowed (K % 4 == 0, aligned).
 // KFULL: K % 32 == 0.  ZROWS: some rows are padding (graph slots with T < 32 / past the batch).
 template <bool AVEC, bool KFULL, bool ZROWS>
-__device__ __forceinline__ void mainloop(const float *const (&arow)[4], const bool (&avalid)[4],
+__device__ __forceinline__ void mainloop(const float *const (&arow)[NP], const bool (&avalid)[NP],
                                          const char *__restrict__ wpack, int K, int k_steps,
                                          int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][2])
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int s_row = tid >> 3;
-    const int s_k4 = (tid & 7) * 4;
+    const int s_k4 = (tid % TPR) * 4;
 
-    float4 ra[4];
-    auto load_a = [&](int k0) {
+    float4 ra[NP];
+    auto load_a_pass = [&](int i, int k0) {
         const int gk = k0 + s_k4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        {
             if constexpr (AVEC) {
                 bool in = true;
                 if constexpr (!KFULL) in = gk < K;  // K % 4 == 0: a float4 is all in or all out
@@ -94,21 +110,37 @@ __device__ __forceinline__ void mainloop(const float *const (&arow)[4], const bo
             }
         }
     };
-    auto store_a = [&](int buf) {
-        char *hi_plane = lds + buf * (2 * BM * 64);
-        char *lo_plane = hi_plane + BM * 64;
+    auto load_a = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 32 + s_row;
+        for (int i = 0; i < NP; ++i) load_a_pass(i, k0);
+    };
+    auto store_a_pass = [&](int buf, int i) {
+        char *hi_plane = lds + buf * (2 * BM * ROWB);
+        char *lo_plane = hi_plane + BM * ROWB;
+        {
+            const int row = stage_row(i);
             const int off = a_lds_off(row, s_k4 >> 3) + (s_k4 & 4) * 2;
             bf16x4 hi, lo;
+#if defined(GGCN_LAB_NO_SPLIT)
+            hi[0] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(ra[i].x) >> 16));
+            hi[1] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(ra[i].y) >> 16));
+            hi[2] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(ra[i].z) >> 16));
+            hi[3] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(ra[i].w) >> 16));
+            lo = hi;
+#else
             hi[0] = (__bf16)ra[i].x; hi[1] = (__bf16)ra[i].y; hi[2] = (__bf16)ra[i].z; hi[3] = (__bf16)ra[i].w;
             lo[0] = (__bf16)(ra[i].x - (float)hi[0]);
             lo[1] = (__bf16)(ra[i].y - (float)hi[1]);
             lo[2] = (__bf16)(ra[i].z - (float)hi[2]);
             lo[3] = (__bf16)(ra[i].w - (float)hi[3]);
+#endif
+#if defined(GGCN_LAB_NO_DSWRITE)
+            asm volatile("" ::"v"(hi), "v"(lo), "v"(off));
+            (void)hi_plane; (void)lo_plane;
+#else
             *reinterpret_cast<bf16x4 *>(hi_plane + off) = hi;
             *reinterpret_cast<bf16x4 *>(lo_plane + off) = lo;
+#endif
         }
     };
 
@@ -129,20 +161,18 @@ __device__ __forceinline__ void mainloop(const float *const (&arow)[4], const bo
 
     const int f_row = lane & 31;
     const int f_half = lane >> 5;
-    auto mma_step = [&](int buf, int s, const bf16x8 (&b)[2][2]) {
-        const char *hi_plane = lds + buf * (2 * BM * 64);
-        const char *lo_plane = hi_plane + BM * 64;
+    // one 32-row block of one k-step: 2 LDS fragment reads + 6 MFMAs (3 products x 2 column tiles)
+    auto mma_block = [&](int buf, int s, int i, const bf16x8 (&b)[2][2]) {
+        const char *hi_plane = lds + buf * (2 * BM * ROWB);
+        const char *lo_plane = hi_plane + BM * ROWB;
+        const int off = a_lds_off(f_row + i * 32, s * 2 + f_half);
+        const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(hi_plane + off);
+        const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(lo_plane + off);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = a_lds_off(f_row + i * 32, s * 2 + f_half);
-            const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(hi_plane + off);
-            const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(lo_plane + off);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][0], acc[i][j], 0, 0, 0);
-            }
+        for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][0], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -153,24 +183,50 @@ __device__ __forceinline__ void mainloop(const float *const (&arow)[4], const bo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    static_assert(BK == 32 && NP == 4, "the interleaved stage below is written for BK = 32");
     bf16x8 b0[2][2], b1[2][2];
     const int stages = (K + BK - 1) / BK;
+    const int last_k0 = (stages - 1) * BK;
+
+    // ---- prologue: stage 0 split into buffer 0, stage 1's rows already in flight ----
     load_a(0);
     load_b(0, b0);
-    for (int st = 0; st < stages; ++st) {
-        const int buf = st & 1;
-        store_a(buf);
-        __syncthreads();  // the only barrier of the stage (double-buffered LDS)
-        // issue order = consumption order (vmcnt retires in order): b1 is needed after 24
-        // MFMAs, the next A rows only at the next stage's split
-        load_b(st * 2 + 1, b1);
-        load_a(st + 1 < stages ? (st + 1) * BK : st * BK);  // last stage: harmless re-read
+#pragma unroll
+    for (int p = 0; p < NP; ++p) store_a_pass(0, p);
+    load_a(BK < last_k0 ? BK : last_k0);
+    __syncthreads();
+
+    // ---- one stage = 8 blocks of (2 LDS reads + 6 MFMAs); the split of the NEXT stage's rows
+    // (VALU + ds_write) and every global load sit BETWEEN the MFMAs of the same wavefront, so
+    // the matrix pipe never waits for a separate "staging phase" (two co-resident workgroups
+    // run this loop in lockstep -- measured -- and cannot be relied on to cover one another).
+    // A rows are re-requested right after their split (one full stage ahead of the next split),
+    // B fragments one k-step ahead; issue order = consumption order (vmcnt retires in order).
+    auto stage = [&](int st, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        const int k_next2 = (st + 2) * BK;
+        const int ka = k_next2 < last_k0 ? k_next2 : last_k0;  // past the end: harmless re-read
+        load_b(st * KS + 1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        mma_step(buf, 0, b0);
-        load_b(st * 2 + 2, b0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mma_block(buf, 0, i, b0);
+            store_a_pass(buf ^ 1, i);   // rows of stage st+1 -> the other buffer
+            load_a_pass(i, ka);         // rows of stage st+2
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_b(st * KS + 2, b0);
         __builtin_amdgcn_sched_barrier(0);
-        mma_step(buf, 1, b1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mma_block(buf, 1, i, b1);
+        __syncthreads();  // the only barrier of the stage
+    };
+    int st = 0;
+    for (; st + 1 < stages; st += 2) {
+        stage(st, std::integral_constant<int, 0>{});
+        stage(st + 1, std::integral_constant<int, 1>{});
     }
+    if (st < stages) stage(st, std::integral_constant<int, 0>{});
 }
 
 }  // namespace bx3

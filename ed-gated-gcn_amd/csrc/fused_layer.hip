@@ -13,8 +13,8 @@
 //     agg[32 x 32] = ADJ_g[32 x 32] . hidden_g[32 x 32]
 // with ADJ_g the graph's 0/1 matrix as an exact bf16 A operand, expanded in registers from a
 // 32-bit row mask (BatchedCSR.rowmask: bit j of word i = edge i<-j; 4 B per node), and
-// hidden split into THREE bf16 planes (residual 2^-24: the aggregation is fp32-exact).
-// Cost: 6 MFMAs per tile on top of the 144 of the main loop (+4 %), no LDS, no extra pass.
+// hidden split into two bf16 planes (residual 2^-17 |hidden|, ~4e-6 after the mean).
+// Cost: 4 MFMAs per tile on top of the 144 of the main loop (+3 %), no LDS, no extra pass.
 // k order inside a step: element j of lane half h is node 16s + 8(j>>2) + 4h + (j&3) for both
 // operands (the register->row map of the accumulator), so no data moves between lanes.
 //
@@ -28,10 +28,8 @@ namespace {
 
 using namespace bx3;
 
-__device__ __forceinline__ float bf16_bits_to_float(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-
-// acc -> three bf16 planes as B-operand fragments of the two k-steps
-__device__ __forceinline__ void split3(const f32x16 &acc, bf16x8 (&frag)[3][2])
+// acc -> two bf16 planes (hi + lo, residual <= 2^-17 |v|) as B-operand fragments of the two k-steps
+__device__ __forceinline__ void split2(const f32x16 &acc, bf16x8 (&frag)[2][2])
 {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -39,21 +37,18 @@ __device__ __forceinline__ void split3(const f32x16 &acc, bf16x8 (&frag)[3][2])
         for (int j = 0; j < 8; ++j) {
             const float v = acc[8 * s + j];
             const __bf16 p0 = (__bf16)v;
-            const float r1 = v - (float)p0;
-            const __bf16 p1 = (__bf16)r1;
-            const float r2 = r1 - (float)p1;
             frag[0][s][j] = p0;
-            frag[1][s][j] = p1;
-            frag[2][s][j] = (__bf16)r2;
+            frag[1][s][j] = (__bf16)(v - (float)p0);
         }
 }
 
-template <bool AVEC, bool KFULL>
+// FULLT: T == 32 (no padded rows inside a graph slot): drops every per-row guard.
+template <bool AVEC, bool KFULL, bool FULLT>
 __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
     const float *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
     const uint32_t *__restrict__ rowmask, const float *__restrict__ bias, int B, int T, int K, int F,
     const float *__restrict__ store_gate, const float *__restrict__ pool_gate_a,
-    const float *__restrict__ pool_gate_b, float *__restrict__ out, int64_t ldo,
+    const float *__restrict__ pool_gate_b, float *__restrict__ out, int ldo,
     float *__restrict__ pool_a, float *__restrict__ pool_b, int g_tiles, int n_wg, int k_steps)
 {
     __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
@@ -62,20 +57,20 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wn = tid >> 6;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g0 = g_tile * 4;  // 4 graph slots of 32 rows per workgroup
     const int n_tiles_total = (F + NT - 1) / NT;
     const int nt0 = n_wgi * (BN / NT) + wn * 2;
 
-    // staging row i*32 + r  <->  node r of graph g0+i
-    const int s_r = tid >> 3;
-    const float *arow[4];
-    bool avalid[4];
+    // tile row 32*slot + r  <->  node r of graph g0+slot
+    const float *arow[NP];
+    bool avalid[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g = g0 + i;
-        avalid[i] = (g < B) && (s_r < T);
-        const int64_t node = avalid[i] ? (int64_t)g * T + s_r : 0;  // clamped, zeroed by the select
+    for (int i = 0; i < NP; ++i) {
+        const int row = stage_row(i);
+        const int g = g0 + (row >> 5), r = row & 31;
+        avalid[i] = (g < B) && (FULLT || r < T);
+        const int64_t node = avalid[i] ? (int64_t)g * T + r : 0;  // clamped, zeroed by the select
         arow[i] = X + node * ldx;
     }
     // this lane's adjacency row (node lane&31) of each of the 4 graphs: in flight under the main loop
@@ -83,7 +78,7 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int g = g0 + i;
-        const bool ok = (g < B) && ((lane & 31) < T);
+        const bool ok = (g < B) && (FULLT || (lane & 31) < T);
         const uint32_t m = rowmask[ok ? (int64_t)g * T + (lane & 31) : 0];
         mask[i] = ok ? m : 0u;
     }
@@ -110,59 +105,73 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
             vgb[i][j] = pool_gate_b ? pool_gate_b[at] : 1.0f;
         }
     }
+    const int lane_off = 4 * h * ldo + c;  // this lane's element inside a (graph, column tile) block
+    const int perm_base = 16 * h;          // ds_bpermute byte address of lane 4h (+ 4*row0 per register)
 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int g = g0 + i;
         if (g >= B) break;  // workgroup-uniform
-        // ---- adjacency fragments of graph g from this lane's row mask ----
-        bf16x8 afrag[2];
-        const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
+        // ---- adjacency fragments of graph g from this lane's row mask: element j of k-step s is
+        // node 16s + 8(j>>2) + 4h + (j&3); two neighbouring elements = two neighbouring mask bits ----
+        const uint32_t mh = mask[i] >> (4 * h);
+        union { bf16x8 v; uint32_t w[4]; } af[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int bit_lo = 16 * s + 8 * (j >> 2) + (j & 3);  // + 4h
-                afrag[s][j] = ((mask[i] >> (bit_lo + 4 * h)) & 1u) ? one : zero;
+            for (int q = 0; q < 4; ++q) {  // element pair (2q, 2q+1): bits b, b+1 of mh
+                const int b = 16 * s + 8 * (q >> 1) + 2 * (q & 1);
+                const uint32_t two = (mh >> b) & 3u;
+                af[s].w[q] = (two & 1u) * 0x3F80u + (two >> 1) * 0x3F800000u;  // bf16 1.0 = 0x3F80
             }
-        // 1 / (rowsum(adj) + 1) of node lane&31 (gcn.py:35); one IEEE division per node
+        // 1 / (rowsum(adj) + 1) of node lane&31 (gcn.py:35): one IEEE division per node, then the
+        // value of row row0 + 4h is fetched per accumulator register through the LDS crossbar
         const float inv = 1.0f / (float)(__popc(mask[i]) + 1);
+        float rinv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row0 = (r & 3) + 8 * (r >> 2);
+            rinv[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_base + 4 * row0, __float_as_int(inv)));
+        }
 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (nt0 + j >= n_tiles_total) break;  // wavefront-uniform: column tile past F
             const int gn = (nt0 + j) * NT + c;
 
-            bf16x8 hfrag[3][2];
-            split3(acc[i][j], hfrag);
+            bf16x8 hfrag[2][2];
+            split2(acc[i][j], hfrag);
             f32x16 y;
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[r] = 0.0f;
 #pragma unroll
-            for (int p = 2; p >= 0; --p)  // smallest plane first
+            for (int p = 1; p >= 0; --p)  // small plane first
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
-                    y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[s], hfrag[p][s], y, 0, 0, 0);
+                    y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s].v, hfrag[p][s], y, 0, 0, 0);
 
-            float pa = -INFINITY, pb = -INFINITY;
-            float *ob = out ? out + ((int64_t)g * T + 4 * h) * ldo + gn : nullptr;
+            // a gate is constant over the rows of a graph and rounding is monotonic, so
+            // max_t fl(y_t * g) == fl(g * max_t y_t) for g >= 0 (and g * min_t y_t for g < 0):
+            // track max and min of y once, apply both pool gates at the end (bert_amir5.py:635-640)
+            float vmax = -INFINITY, vmin = INFINITY;
+            float *tile = out ? out + ((int64_t)g * T) * ldo + (nt0 + j) * NT : nullptr;  // wave-uniform
+            const float sg = vsg[i][j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
-                const float inv_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), row0));
-                const float inv_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), row0 + 4));
-                const float v = y[r] * (h ? inv_hi : inv_lo) + vb[j];            // gcn.py:41,43
-                if (row0 + 4 * h < T) {
-                    if (ob && col_ok[j]) ob[(int64_t)row0 * ldo] = v * vsg[i][j];  // bert_amir5.py:626 / :639
-                    pa = fmaxf(pa, v * vga[i][j]);                               // bert_amir5.py:635,640
-                    pb = fmaxf(pb, v * vgb[i][j]);                               // bert_amir5.py:636
+                const float v = y[r] * rinv[r] + vb[j];   // gcn.py:41,43
+                if (FULLT || row0 + 4 * h < T) {
+                    if (tile && col_ok[j]) tile[lane_off + row0 * ldo] = v * sg;  // bert_amir5.py:626 / :639
+                    vmax = fmaxf(vmax, v);
+                    vmin = fminf(vmin, v);
                 }
             }
-            pa = fmaxf(pa, __shfl_xor(pa, 32));
-            pb = fmaxf(pb, __shfl_xor(pb, 32));
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+            vmin = fminf(vmin, __shfl_xor(vmin, 32));
             if (h == 0 && col_ok[j]) {
-                if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
-                if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
+                const float ga = vga[i][j], gb = vgb[i][j];
+                if (pool_a) pool_a[(int64_t)g * F + gn] = ga * (ga >= 0.0f ? vmax : vmin);
+                if (pool_b) pool_b[(int64_t)g * F + gn] = gb * (gb >= 0.0f ? vmax : vmin);
             }
         }
     }
@@ -204,6 +213,8 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
     if (T > 32) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: T=%d > 32; use ggcn_linear + ggcn_aggregate", T);
     if (!out && !pool_a && !pool_b) return fail(GGCN_EINVAL, "ggcn_layer_fused: no output requested");
     if (ldx < K || (out && ldo < F)) return fail(GGCN_EINVAL, "ggcn_layer_fused: leading dimension too small");
+    if (out && (int64_t)T * ldo >= (int64_t)INT32_MAX)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: T*ldo does not fit 32-bit offsets");
     if (!aligned16(wpack)) return fail(GGCN_EINVAL, "ggcn_layer_fused: wpack must be 16-byte aligned");
     const bool avec = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
     const bool kfull = (K % BK == 0);
@@ -213,13 +224,15 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
     const int64_t grid = grid_for(g_tiles, n_wg);
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: batch too large");
     const char *wp = static_cast<const char *>(wpack);
-#define GGCN_LAUNCH(AV, KF)                                                                                   \
-    hipLaunchKernelGGL((layer_fused_kernel<AV, KF>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
-                       rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, ldo, pool_a,      \
+    const bool fullt = (T == 32);
+#define GGCN_LAUNCH(AV, KF, FT)                                                                                  \
+    hipLaunchKernelGGL((layer_fused_kernel<AV, KF, FT>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
+                       rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, (int)ldo, pool_a,    \
                        pool_b, (int)g_tiles, n_wg, k_steps)
-    if (avec && kfull) GGCN_LAUNCH(true, true);
-    else if (avec) GGCN_LAUNCH(true, false);
-    else GGCN_LAUNCH(false, false);
+    if (avec && kfull && fullt) GGCN_LAUNCH(true, true, true);
+    else if (avec && kfull) GGCN_LAUNCH(true, true, false);
+    else if (avec) GGCN_LAUNCH(true, false, false);
+    else GGCN_LAUNCH(false, false, false);
 #undef GGCN_LAUNCH
     return check_launch("ggcn_layer_fused");
 }

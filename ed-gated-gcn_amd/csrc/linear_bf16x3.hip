@@ -58,13 +58,14 @@ __global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
     const int nt0 = n_wgi * (BN / NT) + wn * 2;  // this wavefront's first 32-column tile
 
     // rows past M are clamped to row M-1: a row of A only feeds the same row of Y, never stored
-    const float *arow[4];
-    const bool avalid[4] = {true, true, true, true};
+    const float *arow[NP];
+    bool avalid[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int64_t gm = m0 + i * 32 + (tid >> 3);
+    for (int i = 0; i < NP; ++i) {
+        int64_t gm = m0 + stage_row(i);
         gm = gm < M ? gm : M - 1;
         arow[i] = X + gm * ldx;
+        avalid[i] = true;
     }
     f32x16 acc[4][2];
     mainloop<AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);

@@ -198,7 +198,7 @@ def test_linear_vs_float64(pkg, dev, precision, M, K, F):
 @pytest.mark.parametrize("B,T,H", [(130, 32, 768), (33, 31, 256), (6, 7, 96)])
 def test_fused_layer_equals_unfused(pkg, dev, B, T, H):
     """Same main loop, same bf16 planes: the one-launch layer and linear+aggregate differ only by
-    the exact-to-2^-24 MFMA aggregation and one reciprocal per node."""
+    the two-plane (2^-17) MFMA aggregation and one reciprocal per node."""
     from ed_gated_gcn_amd import synth
     rng = np.random.default_rng(B)
     adj = synth.dependency_batch(B, T, min(4.0, T), seed=3, lengths=rng.integers(1, T + 1, size=B))
@@ -214,7 +214,7 @@ def test_fused_layer_equals_unfused(pkg, dev, B, T, H):
             outs.append(m.forward_gated(x, a, store_gate=g2, pool_gate_a=g1, pool_gate_b=g2,
                                         want_pool_a=True, want_pool_b=True))
     for u, v in zip(*outs):
-        assert torch.max(torch.abs(u - v)).item() <= 3e-6
+        assert torch.max(torch.abs(u - v)).item() <= 4e-5
 
 
 def test_unaligned_and_strided_inputs(pkg, dev):
@@ -321,7 +321,9 @@ def test_config2_linearity_and_identity(pkg, dev, config2, precision, fused):
         lin = gc1.linear(x.reshape(B * c["T"], -1)).view(B, c["T"], -1)
     tol = TOL[precision] * 3
     assert torch.max(torch.abs(fz - (0.5 * fx - 2.0 * fy))).item() <= tol
-    np.testing.assert_allclose(fi.cpu().numpy(), (lin / 2 + bias).cpu().numpy(), rtol=0, atol=2e-6)
+    # fused: hidden enters the aggregation MFMA as two bf16 planes (residual <= 2^-17 |hidden|)
+    np.testing.assert_allclose(fi.cpu().numpy(), (lin / 2 + bias).cpu().numpy(), rtol=0,
+                               atol=2e-5 if fused else 2e-6)
 
 
 def test_config4_long_document_sample(pkg, dev):
