@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--precision", default=os.environ.get("GGCN_PRECISION", "bf16x3"), choices=["bf16x3", "fp32"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --graphs per GPU; strong: --graphs in total, sharded (BASELINE configs[2])")
+    ap.add_argument("--unfused", action="store_true", help="force linear + aggregate (2 launches per layer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-graphs", type=int, default=4096, help="sample size of the CPU baseline")
     return ap.parse_args()
@@ -106,6 +107,8 @@ def main():
     pkg.load_library()
     B_total = args.graphs * world if args.scaling == "weak" else args.graphs
     B = args.graphs if args.scaling == "weak" else (args.graphs // world)
+    if args.scaling == "strong" and args.graphs % world:
+        raise SystemExit("--scaling strong needs --graphs divisible by the number of GPUs")
     T, H = args.tokens, args.hidden
 
     # ---- synthetic batch of this rank, resident in HBM before timing --------
@@ -124,21 +127,30 @@ def main():
     for w, b in ((w1, b1), (w2, b2)):
         m = pkg.GraphConvolution(H, H, opt=None).to(dev)
         m.precision = args.precision
+        m.fused = not args.unfused
         with torch.no_grad():
             m.weight.copy_(torch.from_numpy(w))
             m.bias.copy_(torch.from_numpy(b))
         layers.append(m.eval())
     gc1, gc2 = layers
-    gathered = torch.empty(world * B, H, device=dev) if world > 1 else None
+    # the path's only collective: all-gather of the per-shard pooled outputs [B_r, H], launched
+    # asynchronously so step i's gather (RCCL's stream, xGMI) overlaps step i+1's kernels
+    from ed_gated_gcn_amd import shard
+    gather = shard.PooledGather([B] * world, H, dev) if world > 1 else None
+    pending = []
 
     def step():
         with torch.no_grad():
             r = pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2)
             if world > 1:
-                dist.all_gather_into_tensor(gathered, r["out"])
+                if pending:
+                    gather.finish(pending.pop())      # step i-1's gather: done or nearly done
+                pending.append(gather.start(r["out"]))
         return r
 
     def sync_all():
+        while pending:
+            gather.finish(pending.pop())
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -175,48 +187,63 @@ def main():
         return statistics.mean(a.elapsed_time(b) for a, b in evs) * 1e-3  # seconds
 
     n_prof = max(10, min(args.steps, 50))
-    x2d = x.view(B * T, H)
-    with torch.no_grad():
-        hidden = gc1.linear(x2d)
-        t_lin = time_kernel(lambda: gc1.linear(x2d), n_prof)
-    # aggregation alone (layer-1 form: ungated store + two gated pools), through the C ABI
     from ed_gated_gcn_amd import _capi
     lib = pkg.load_library()
-    out = torch.empty(B * T, H, device=dev)
-    pa = torch.empty(B, H, device=dev)
-    pb = torch.empty(B, H, device=dev)
-
-    def agg_once():
-        _capi.check(lib.ggcn_aggregate(_capi.ptr(hidden), H, _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), None,
-                                       _capi.ptr(gc1.bias.detach()), B, T, H, None, _capi.ptr(g1), _capi.ptr(g2),
-                                       _capi.ptr(out), H, _capi.ptr(pa), _capi.ptr(pb), _capi.stream_of(dev)),
-                    "ggcn_aggregate")
-    agg_once()
-    t_agg = time_kernel(agg_once, n_prof)
-
     N = B * T
-    lin_flops = 2.0 * N * H * H                       # algorithmic flops of gcn.py:34 per launch
-    agg_bytes = 2 * 4 * N * H + 4 * (N + 1) + 4 * nnz + 2 * 4 * B * H + 4 * H   # SURVEY 8d minus W
+    x2d = x.view(B * T, H)
+    layer_bytes = synth.algorithmic_bytes_per_layer(B, T, H, nnz, n_gates=2)   # SURVEY 8d, layer-1 form
     fwd_bytes = 2 * synth.algorithmic_bytes_per_layer(B, T, H, nnz)
+    lin_flops = 2.0 * N * H * H                       # algorithmic flops of gcn.py:34 per launch
+    agg_flops = 2.0 * nnz * H                         # gcn.py:41 on the non-zeros
     lin_peak = MFMA_BF16_PEAK_TF if args.precision == "bf16x3" else MFMA_F32_PEAK_TF
-    lin_tf = lin_flops / t_lin / 1e12
-    dominant_is_linear = t_lin >= t_agg
-    if dominant_is_linear:
-        roofline = {"kernel": "linear_%s_kernel" % args.precision, "bound": "mfma", "achieved": lin_tf,
-                    "peak": lin_peak, "unit": "TFLOP/s", "frac": lin_tf / lin_peak, "traffic": None,
-                    "avg_launch_us": t_lin * 1e6,
-                    "note": "achieved = algorithmic 2*N*K*F flops / launch; bf16x3 issues 3 bf16 MFMA flops "
-                            "per algorithmic flop, so its ceiling on this peak is 1/3"
-                            if args.precision == "bf16x3" else "exact f32-input MFMA"}
+    fused_path = gc1.fused and args.precision == "bf16x3" and csr.rowmask is not None and csr.vals is None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch, if recorded
+    measured = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    kernels = {}
+    if fused_path:
+        with torch.no_grad():
+            t_fused = time_kernel(lambda: gc1.forward_gated(x, csr, pool_gate_a=g1, pool_gate_b=g2,
+                                                            want_pool_a=True, want_pool_b=True), n_prof)
+        tf = (lin_flops + agg_flops) / t_fused / 1e12
+        traffic = measured.get("layer_fused_kernel")
+        roofline = {"kernel": "layer_fused_kernel", "bound": "mfma", "achieved": tf, "peak": lin_peak,
+                    "unit": "TFLOP/s", "frac": tf / lin_peak, "traffic": traffic, "avg_launch_us": t_fused * 1e6,
+                    "algorithmic_flops_per_launch": lin_flops + agg_flops,
+                    "algorithmic_bytes_per_launch": layer_bytes,
+                    "hbm_GBps": layer_bytes / t_fused / 1e9, "hbm_frac": layer_bytes / t_fused / 1e9 / HBM_PEAK_GBS,
+                    "note": "achieved = algorithmic (2*N*K*F + 2*nnz*F) flops / launch; the bf16x3 linear issues 3 "
+                            "bf16 MFMA flops per algorithmic flop, so its ceiling on this peak is 1/3 (833 TFLOP/s)"}
+        kernels["layer_fused"] = {"avg_launch_us": t_fused * 1e6, "algorithmic_tflops": tf, "launches_per_step": 2}
     else:
-        gbs = agg_bytes / t_agg / 1e9
-        roofline = {"kernel": "aggregate_rows", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_agg * 1e6}
-    kernels = {
-        "linear": {"avg_launch_us": t_lin * 1e6, "algorithmic_tflops": lin_tf, "launches_per_step": 2},
-        "aggregate": {"avg_launch_us": t_agg * 1e6, "algorithmic_GBps": agg_bytes / t_agg / 1e9,
-                      "hbm_frac": agg_bytes / t_agg / 1e9 / HBM_PEAK_GBS, "launches_per_step": 2},
-    }
+        with torch.no_grad():
+            hidden = gc1.linear(x2d)
+            t_lin = time_kernel(lambda: gc1.linear(x2d), n_prof)
+        out = torch.empty(B * T, H, device=dev)
+        pa = torch.empty(B, H, device=dev)
+        pb = torch.empty(B, H, device=dev)
+
+        def agg_once():   # aggregation alone, layer-1 form, through the C ABI
+            _capi.check(lib.ggcn_aggregate(_capi.ptr(hidden), H, _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx),
+                                           _capi.ptr(csr.vals), _capi.ptr(gc1.bias.detach()), B, T, H, None,
+                                           _capi.ptr(g1), _capi.ptr(g2), _capi.ptr(out), H, _capi.ptr(pa),
+                                           _capi.ptr(pb), _capi.stream_of(dev)), "ggcn_aggregate")
+        agg_once()
+        t_agg = time_kernel(agg_once, n_prof)
+        agg_bytes = layer_bytes - 4 * H * H
+        lin_tf = lin_flops / t_lin / 1e12
+        if t_lin >= t_agg:
+            roofline = {"kernel": "linear_%s_kernel" % args.precision, "bound": "mfma", "achieved": lin_tf,
+                        "peak": lin_peak, "unit": "TFLOP/s", "frac": lin_tf / lin_peak,
+                        "traffic": measured.get("linear_%s_kernel" % args.precision), "avg_launch_us": t_lin * 1e6}
+        else:
+            gbs = agg_bytes / t_agg / 1e9
+            roofline = {"kernel": "aggregate_rows", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": measured.get("aggregate_rows"),
+                        "avg_launch_us": t_agg * 1e6}
+        kernels["linear"] = {"avg_launch_us": t_lin * 1e6, "algorithmic_tflops": lin_tf, "launches_per_step": 2}
+        kernels["aggregate"] = {"avg_launch_us": t_agg * 1e6, "algorithmic_GBps": agg_bytes / t_agg / 1e9,
+                                "hbm_frac": agg_bytes / t_agg / 1e9 / HBM_PEAK_GBS, "launches_per_step": 2}
 
     result = None
     if rank == 0:
@@ -231,6 +258,7 @@ def main():
                                    "(nnz %d incl. self loops), hidden %d, 2 gated-GCN layers, fp32 in/out"
                                    % (B, T, args.degree, nnz, H),
                        "graphs_total": B_total, "precision": args.precision,
+                       "path": "fused (1 launch/layer)" if fused_path else "linear + aggregate (2 launches/layer)",
                        "collective": "all_gather(out[B,H])" if world > 1 else "none"},
             "edge_layers_per_sec": 2 * value,
             "forward_algorithmic_bytes": fwd_bytes,

@@ -45,6 +45,8 @@ def time_variants(what, names):
     csr = pkg.BatchedCSR.from_arrays(rowptr, colidx, B, T, dev)
     gen = torch.Generator().manual_seed(1)
     x = torch.randn(N, H, generator=gen).to(dev)
+    if os.environ.get("LAB_ZERO_X"):
+        x.zero_()
     g1 = torch.sigmoid(torch.randn(B, H, generator=gen)).to(dev)
     g2 = torch.sigmoid(torch.randn(B, H, generator=gen)).to(dev)
     w, b = synth.layer_params(H, H, seed=1)
