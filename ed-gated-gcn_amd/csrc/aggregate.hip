@@ -27,87 +27,75 @@
 // + 4*B*F per gate + 4*F.
 #include "common.h"
 
+#include <hip/hip_fp16.h>
+
 #include <cfloat>
 
 namespace ggcn {
 namespace {
 
-template <int VEC>
-struct Vec;
-template <>
-struct Vec<4> {
-    using type = float4;
-};
-template <>
-struct Vec<1> {
-    using type = float;
-};
-
-__device__ __forceinline__ float4 ld(const float4 *p) { return *p; }
-__device__ __forceinline__ float ld(const float *p) { return *p; }
-__device__ __forceinline__ float4 splat4(float v) { return make_float4(v, v, v, v); }
-
-__device__ __forceinline__ void fma_sel(float4 &acc, bool on, float w, const float4 &h)
-{
-    if (on) {
-        acc.x = fmaf(w, h.x, acc.x);
-        acc.y = fmaf(w, h.y, acc.y);
-        acc.z = fmaf(w, h.z, acc.z);
-        acc.w = fmaf(w, h.w, acc.w);
-    }
-}
-__device__ __forceinline__ void fma_sel(float &acc, bool on, float w, const float &h)
-{
-    if (on) acc = fmaf(w, h, acc);
-}
-__device__ __forceinline__ void add_sel(float4 &acc, bool on, const float4 &h)
-{
-    if (on) {
-        acc.x += h.x;
-        acc.y += h.y;
-        acc.z += h.z;
-        acc.w += h.w;
-    }
-}
-__device__ __forceinline__ void add_sel(float &acc, bool on, const float &h)
-{
-    if (on) acc += h;
-}
-
-// y = acc / denom + bias ; IEEE division like torch's `/` (gcn.py:41)
-__device__ __forceinline__ float4 finish(const float4 &a, float denom, const float4 &b)
-{
-    return make_float4(a.x / denom + b.x, a.y / denom + b.y, a.z / denom + b.z, a.w / denom + b.w);
-}
-__device__ __forceinline__ float finish(const float &a, float denom, const float &b) { return a / denom + b; }
-
-__device__ __forceinline__ float4 mul(const float4 &a, const float4 &b)
-{
-    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
-}
-__device__ __forceinline__ float mul(const float &a, const float &b) { return a * b; }
-__device__ __forceinline__ float4 vmax(const float4 &a, const float4 &b)
-{
-    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
-}
-__device__ __forceinline__ float vmax(const float &a, const float &b) { return fmaxf(a, b); }
-
-__device__ __forceinline__ void st_lds(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
-__device__ __forceinline__ void st_lds(float *p, const float &v) { *p = v; }
-
 constexpr int kWaves = 4;
 
-// grid.x = B * n_slabs ; block = 256.  slab = 64*VEC columns.
-template <int VEC, bool HAS_VALS>
+// VEC consecutive feature elements of one row as one global access: fp32 x4 / fp16 x8 = 16 B
+// (one coalesced 1 KiB read per wavefront), or a single element for unaligned shapes.
+template <typename E, int VEC>
+struct Seg;
+template <>
+struct Seg<float, 4> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[4])
+    {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float *p, const float (&v)[4])
+    {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <>
+struct Seg<float, 1> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void store(float *p, const float (&v)[1]) { *p = v[0]; }
+};
+template <>
+struct Seg<__half, 8> {
+    static __device__ __forceinline__ void load(const __half *p, float (&v)[8])
+    {
+        const uint4 t = *reinterpret_cast<const uint4 *>(p);
+        const __half2 *h = reinterpret_cast<const __half2 *>(&t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 f = __half22float2(h[i]);
+            v[2 * i] = f.x;
+            v[2 * i + 1] = f.y;
+        }
+    }
+    static __device__ __forceinline__ void store(__half *p, const float (&v)[8])
+    {
+        uint4 t;
+        __half2 *h = reinterpret_cast<__half2 *>(&t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = __floats2half2_rn(v[2 * i], v[2 * i + 1]);
+        *reinterpret_cast<uint4 *>(p) = t;
+    }
+};
+template <>
+struct Seg<__half, 1> {
+    static __device__ __forceinline__ void load(const __half *p, float (&v)[1]) { v[0] = __half2float(*p); }
+    static __device__ __forceinline__ void store(__half *p, const float (&v)[1]) { *p = __float2half_rn(v[0]); }
+};
+
+// grid.x = B * n_slabs ; block = 256.  slab = 64*VEC columns.  E = feature element type
+// (float, or __half with fp32 accumulation: BASELINE configs[3]); bias, gates, pools are fp32.
+template <typename E, int VEC, bool HAS_VALS>
 __global__ __launch_bounds__(256) void aggregate_rows(
-    const float *__restrict__ Hd, int64_t ldh, const int32_t *__restrict__ rowptr,
+    const E *__restrict__ Hd, int64_t ldh, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ colidx, const float *__restrict__ vals,
     const float *__restrict__ bias, int T, int F, int n_slabs,
     const float *__restrict__ store_gate, const float *__restrict__ pool_gate_a,
-    const float *__restrict__ pool_gate_b, float *__restrict__ out, int64_t ldo,
+    const float *__restrict__ pool_gate_b, E *__restrict__ out, int64_t ldo,
     float *__restrict__ pool_a, float *__restrict__ pool_b)
 {
-    using V = typename Vec<VEC>::type;
     constexpr int kSlab = kWave * VEC;
     __shared__ float red[2][kWaves][kSlab];
 
@@ -118,26 +106,31 @@ __global__ __launch_bounds__(256) void aggregate_rows(
     const int col = slab * kSlab + lane * VEC;
     const bool live = col < F;  // F % VEC == 0 is checked on the host
 
-    const V one = [] { if constexpr (VEC == 4) return splat4(1.0f); else return 1.0f; }();
-    const V zero = [] { if constexpr (VEC == 4) return splat4(0.0f); else return 0.0f; }();
-    const V ninf = [] { if constexpr (VEC == 4) return splat4(-INFINITY); else return -INFINITY; }();
-
-    V vb = zero, vsg = one, vga = one, vgb = one;
+    float vb[VEC], vsg[VEC], vga[VEC], vgb[VEC], pa[VEC], pb[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        vb[k] = 0.0f; vsg[k] = 1.0f; vga[k] = 1.0f; vgb[k] = 1.0f;
+        pa[k] = -INFINITY; pb[k] = -INFINITY;
+    }
     if (live) {
         const int64_t g = (int64_t)b * F + col;
-        if (bias) vb = ld(reinterpret_cast<const V *>(bias + col));
-        if (store_gate) vsg = ld(reinterpret_cast<const V *>(store_gate + g));
-        if (pool_gate_a) vga = ld(reinterpret_cast<const V *>(pool_gate_a + g));
-        if (pool_gate_b) vgb = ld(reinterpret_cast<const V *>(pool_gate_b + g));
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {  // contiguous: the compiler merges these into 16-B loads
+            if (bias) vb[k] = bias[col + k];
+            if (store_gate) vsg[k] = store_gate[g + k];
+            if (pool_gate_a) vga[k] = pool_gate_a[g + k];
+            if (pool_gate_b) vgb[k] = pool_gate_b[g + k];
+        }
     }
-    V pa = ninf, pb = ninf;
 
-    const float *hcol = Hd + col;
+    const E *hcol = Hd + col;
     for (int t = wave; t < T; t += kWaves) {
         const int64_t row = (int64_t)b * T + t;
         const int beg = rowptr[row];
         const int end = rowptr[row + 1];
-        V acc = zero;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
         float wsum = 0.0f;
         for (int e = beg; e < end; e += 4) {
             // wave-uniform neighbour ids / weights: scalar loads
@@ -146,53 +139,70 @@ __global__ __launch_bounds__(256) void aggregate_rows(
             const int c1 = v1 ? colidx[e + 1] : c0;
             const int c2 = v2 ? colidx[e + 2] : c0;
             const int c3 = v3 ? colidx[e + 3] : c0;
-            V h0 = zero, h1 = zero, h2 = zero, h3 = zero;
-            if (live) {  // four independent 1 KiB row-segment reads in flight
-                h0 = ld(reinterpret_cast<const V *>(hcol + (int64_t)c0 * ldh));
-                h1 = ld(reinterpret_cast<const V *>(hcol + (int64_t)c1 * ldh));
-                h2 = ld(reinterpret_cast<const V *>(hcol + (int64_t)c2 * ldh));
-                h3 = ld(reinterpret_cast<const V *>(hcol + (int64_t)c3 * ldh));
+            float h0[VEC], h1[VEC], h2[VEC], h3[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) h0[k] = h1[k] = h2[k] = h3[k] = 0.0f;
+            if (live) {  // four independent row-segment reads in flight (1 KiB each per wavefront)
+                Seg<E, VEC>::load(hcol + (int64_t)c0 * ldh, h0);
+                Seg<E, VEC>::load(hcol + (int64_t)c1 * ldh, h1);
+                Seg<E, VEC>::load(hcol + (int64_t)c2 * ldh, h2);
+                Seg<E, VEC>::load(hcol + (int64_t)c3 * ldh, h3);
             }
             if constexpr (HAS_VALS) {
                 const float w0 = vals[e];
                 const float w1 = v1 ? vals[e + 1] : 0.0f;
                 const float w2 = v2 ? vals[e + 2] : 0.0f;
                 const float w3 = v3 ? vals[e + 3] : 0.0f;
-                fma_sel(acc, true, w0, h0);
-                fma_sel(acc, v1, w1, h1);
-                fma_sel(acc, v2, w2, h2);
-                fma_sel(acc, v3, w3, h3);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {  // a masked-out neighbour must not contribute 0*inf
+                    acc[k] = fmaf(w0, h0[k], acc[k]);
+                    if (v1) acc[k] = fmaf(w1, h1[k], acc[k]);
+                    if (v2) acc[k] = fmaf(w2, h2[k], acc[k]);
+                    if (v3) acc[k] = fmaf(w3, h3[k], acc[k]);
+                }
                 wsum += w0;
                 wsum += w1;
                 wsum += w2;
                 wsum += w3;
             } else {
-                add_sel(acc, true, h0);
-                add_sel(acc, v1, h1);
-                add_sel(acc, v2, h2);
-                add_sel(acc, v3, h3);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    acc[k] += h0[k];
+                    if (v1) acc[k] += h1[k];
+                    if (v2) acc[k] += h2[k];
+                    if (v3) acc[k] += h3[k];
+                }
             }
         }
         const float denom = (HAS_VALS ? wsum : (float)(end - beg)) + 1.0f;  // gcn.py:35
-        const V y = finish(acc, denom, vb);                                  // gcn.py:41,43
         if (live) {
-            if (out) *reinterpret_cast<V *>(out + row * ldo + col) = mul(y, vsg);
-            pa = vmax(pa, mul(y, vga));
-            pb = vmax(pb, mul(y, vgb));
+            float y[VEC], o[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                y[k] = acc[k] / denom + vb[k];  // gcn.py:41,43; IEEE division like torch's `/`
+                o[k] = y[k] * vsg[k];
+                pa[k] = fmaxf(pa[k], y[k] * vga[k]);
+                pb[k] = fmaxf(pb[k], y[k] * vgb[k]);
+            }
+            if (out) Seg<E, VEC>::store(out + row * ldo + col, o);
         }
     }
 
     if (pool_a || pool_b) {
-        st_lds(&red[0][wave][lane * VEC], pa);
-        st_lds(&red[1][wave][lane * VEC], pb);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            red[0][wave][lane * VEC + k] = pa[k];
+            red[1][wave][lane * VEC + k] = pb[k];
+        }
         __syncthreads();
-        const int tcol = slab * kSlab + threadIdx.x;
-        if ((int)threadIdx.x < kSlab && tcol < F) {
-            float ma = red[0][0][threadIdx.x], mb = red[1][0][threadIdx.x];
+        for (int tl = threadIdx.x; tl < kSlab; tl += 256) {
+            const int tcol = slab * kSlab + tl;
+            if (tcol >= F) break;
+            float ma = red[0][0][tl], mb = red[1][0][tl];
 #pragma unroll
             for (int w = 1; w < kWaves; ++w) {
-                ma = fmaxf(ma, red[0][w][threadIdx.x]);
-                mb = fmaxf(mb, red[1][w][threadIdx.x]);
+                ma = fmaxf(ma, red[0][w][tl]);
+                mb = fmaxf(mb, red[1][w][tl]);
             }
             if (pool_a) pool_a[(int64_t)b * F + tcol] = ma;
             if (pool_b) pool_b[(int64_t)b * F + tcol] = mb;
@@ -200,10 +210,10 @@ __global__ __launch_bounds__(256) void aggregate_rows(
     }
 }
 
-template <int VEC>
-int launch(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
+template <typename E, int VEC>
+int launch(const E *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
            const float *vals, const float *bias, int B, int T, int F, const float *sg,
-           const float *ga, const float *gb, float *out, int64_t ldo, float *pa, float *pb,
+           const float *ga, const float *gb, E *out, int64_t ldo, float *pa, float *pb,
            hipStream_t st)
 {
     const int slab = kWave * VEC;
@@ -211,20 +221,16 @@ int launch(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *c
     const int64_t blocks = (int64_t)B * n_slabs;
     if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_aggregate: grid too large");
     if (vals)
-        hipLaunchKernelGGL((aggregate_rows<VEC, true>), dim3((unsigned)blocks), dim3(256), 0, st, Hd, ldh,
+        hipLaunchKernelGGL((aggregate_rows<E, VEC, true>), dim3((unsigned)blocks), dim3(256), 0, st, Hd, ldh,
                            rowptr, colidx, vals, bias, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb);
     else
-        hipLaunchKernelGGL((aggregate_rows<VEC, false>), dim3((unsigned)blocks), dim3(256), 0, st, Hd, ldh,
+        hipLaunchKernelGGL((aggregate_rows<E, VEC, false>), dim3((unsigned)blocks), dim3(256), 0, st, Hd, ldh,
                            rowptr, colidx, vals, bias, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb);
     return check_launch("ggcn_aggregate");
 }
 
-}  // namespace
-
-int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
-              const float *vals, const float *bias, int B, int T, int F, const float *store_gate,
-              const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
-              float *pool_a, float *pool_b, hipStream_t st)
+int check_args(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx, int B, int T, int F,
+               const void *out, int64_t ldo, const float *pool_a, const float *pool_b)
 {
     if (!Hd || !rowptr || !colidx) return fail(GGCN_EINVAL, "ggcn_aggregate: null input pointer");
     if (B <= 0 || T <= 0 || F <= 0)
@@ -234,15 +240,39 @@ int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t
         return fail(GGCN_EINVAL, "ggcn_aggregate: leading dimension smaller than F=%d", F);
     if ((int64_t)B * T >= (int64_t)INT32_MAX)
         return fail(GGCN_EUNSUPPORTED, "ggcn_aggregate: B*T does not fit int32 node ids");
-    const bool vec = (F % 4 == 0) && (ldh % 4 == 0) && aligned16(Hd) &&
-                     (!out || ((ldo % 4 == 0) && aligned16(out))) && (!bias || aligned16(bias)) &&
-                     (!store_gate || aligned16(store_gate)) && (!pool_gate_a || aligned16(pool_gate_a)) &&
-                     (!pool_gate_b || aligned16(pool_gate_b));
+    return GGCN_OK;
+}
+
+}  // namespace
+
+int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
+              const float *vals, const float *bias, int B, int T, int F, const float *store_gate,
+              const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
+              float *pool_a, float *pool_b, hipStream_t st)
+{
+    if (int rc = check_args(Hd, ldh, rowptr, colidx, B, T, F, out, ldo, pool_a, pool_b)) return rc;
+    const bool vec = (F % 4 == 0) && (ldh % 4 == 0) && aligned16(Hd) && (!out || ((ldo % 4 == 0) && aligned16(out)));
     if (vec)
-        return launch<4>(Hd, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
-                         pool_gate_b, out, ldo, pool_a, pool_b, st);
-    return launch<1>(Hd, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
-                     pool_gate_b, out, ldo, pool_a, pool_b, st);
+        return launch<float, 4>(Hd, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
+                                pool_gate_b, out, ldo, pool_a, pool_b, st);
+    return launch<float, 1>(Hd, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
+                            pool_gate_b, out, ldo, pool_a, pool_b, st);
+}
+
+int aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
+                const float *vals, const float *bias, int B, int T, int F, const float *store_gate,
+                const float *pool_gate_a, const float *pool_gate_b, void *out, int64_t ldo,
+                float *pool_a, float *pool_b, hipStream_t st)
+{
+    if (int rc = check_args(Hd, ldh, rowptr, colidx, B, T, F, out, ldo, pool_a, pool_b)) return rc;
+    const __half *h = static_cast<const __half *>(Hd);
+    __half *o = static_cast<__half *>(out);
+    const bool vec = (F % 8 == 0) && (ldh % 8 == 0) && aligned16(Hd) && (!out || ((ldo % 8 == 0) && aligned16(out)));
+    if (vec)
+        return launch<__half, 8>(h, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
+                                 pool_gate_b, o, ldo, pool_a, pool_b, st);
+    return launch<__half, 1>(h, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
+                             pool_gate_b, o, ldo, pool_a, pool_b, st);
 }
 
 }  // namespace ggcn

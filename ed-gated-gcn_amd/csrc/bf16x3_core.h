@@ -27,6 +27,8 @@
 #pragma once
 #include "common.h"
 
+#include <hip/hip_fp16.h>
+
 #include <type_traits>
 
 namespace ggcn {
@@ -36,33 +38,34 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef GGCN_BK
-#define GGCN_BK 32
-#endif
-constexpr int BM = 128, BN = 256, BK = GGCN_BK;  // BK 32 or 64
+constexpr int BM = 128, BN = 256, BK = 32;
 constexpr int KSTEP = 16;             // K per MFMA
 constexpr int KS = BK / KSTEP;        // MFMA k-steps per stage
-constexpr int TPR = BK / 4;           // threads covering one row of a stage (float4 each)
-constexpr int RPP = 256 / TPR;        // rows per staging pass of the workgroup
-constexpr int NP = BM / RPP;          // staging passes (= float4 registers per thread)
-constexpr int ROWB = BK * 2;          // bytes per LDS row of one plane
+constexpr int ROWB = BK * 2;          // bytes per LDS row of one plane (64)
 constexpr int NT = 32;                // columns per MFMA tile
 constexpr int FRAG_BYTES = 64 * 16;   // one B fragment: 64 lanes x 8 bf16
 constexpr int kThreads = 256;
-constexpr int kLdsBytes = 2 * 2 * BM * ROWB;  // [buffer][plane][128 rows x ROWB]: 32 KiB (BK 32) / 64 KiB
+constexpr int kLdsBytes = 2 * 2 * BM * ROWB;  // [buffer][plane][128 rows x 64 B] = 32 KiB
+
+// Staging geometry of one 128 x 32 stage of A for element type AT: every thread moves 16 B per
+// pass.  fp32: 8 threads per row, 32 rows per pass, 4 passes;  fp16: 4 per row, 64 rows, 2 passes.
+template <typename AT>
+struct Geom {
+    static constexpr int EPT = 16 / (int)sizeof(AT);  // elements per thread per pass
+    static constexpr int TPR = BK / EPT;              // threads per row
+    static constexpr int RPP = kThreads / TPR;        // rows per pass
+    static constexpr int NP = BM / RPP;               // passes
+};
 
 __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// LDS image of one A plane: [128 rows][ROWB/16 chunks of 16 B].  The chunk index is XORed so
-// that the 16 rows of a ds_read_b128 lane group land on 16 distinct 16-B slots of the 256-B
-// bank row: 64-B rows (4 rows per bank row): chunk ^ (row>>2)&3; 128-B rows: chunk ^ (row>>1)&7.
-__device__ __forceinline__ int a_lds_off(int row, int chunk)
-{
-    if constexpr (BK == 32) return row * ROWB + ((chunk ^ ((row >> 2) & 3)) << 4);
-    else return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
+// LDS image of one A plane: [128 rows][4 chunks of 16 B]; the chunk index is XORed with
+// (row>>2)&3 so that the 16 rows of a ds_read_b128 lane group land on 16 distinct 16-B slots of
+// the 256-B bank row (4 rows of 64 B per bank row).
+__device__ __forceinline__ int a_lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
 // staging row of pass p for this thread
-__device__ __forceinline__ int stage_row(int p) { return p * RPP + (int)threadIdx.x / TPR; }
+template <typename AT>
+__device__ __forceinline__ int stage_row(int p) { return p * Geom<AT>::RPP + (int)threadIdx.x / Geom<AT>::TPR; }
 
 // XCD-aware remap of a 1-D grid: ids congruent mod 8 share an XCD (observed round-robin
 // dispatch; speed only, never correctness); inside one XCD's sequence consecutive ids walk the
@@ -76,71 +79,87 @@ __device__ __forceinline__ bool tile_of_block(int id, int m_tiles, int n_wg, int
 }
 inline int64_t grid_for(int64_t m_tiles, int n_wg) { return (m_tiles + 7) / 8 * 8 * n_wg; }
 
-// arow[i]: this thread's 4 source rows (already clamped to valid memory); avalid[i]: false =>
-// the row is padding and must read as zeros.  AVEC: 16-B loads allowed (K % 4 == 0, aligned).
-// KFULL: K % 32 == 0.  ZROWS: some rows are padding (graph slots with T < 32 / past the batch).
-template <bool AVEC, bool KFULL, bool ZROWS>
-__device__ __forceinline__ void mainloop(const float *const (&arow)[NP], const bool (&avalid)[NP],
+__device__ __forceinline__ float elem_to_float(float v) { return v; }
+__device__ __forceinline__ float elem_to_float(__half v) { return __half2float(v); }
+
+// 16 B of AT from global memory as EPT floats
+template <typename AT>
+__device__ __forceinline__ void load16(const AT *p, float (&v)[Geom<AT>::EPT])
+{
+    if constexpr (sizeof(AT) == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        const uint4 t = *reinterpret_cast<const uint4 *>(p);
+        const __half2 *h = reinterpret_cast<const __half2 *>(&t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 f = __half22float2(h[i]);
+            v[2 * i] = f.x;
+            v[2 * i + 1] = f.y;
+        }
+    }
+}
+
+// arow[i]: this thread's NP source rows (already clamped to valid memory); avalid[i]: false =>
+// the row is padding and must read as zeros.  AT: element type of A (float or __half: an fp16
+// value is exactly hi + lo, so the same three products apply).  AVEC: 16-B loads allowed
+// (K % EPT == 0, aligned).  KFULL: K % 32 == 0.  ZROWS: some rows are padding (graph slots with
+// T < 32 / past the batch).
+template <typename AT, bool AVEC, bool KFULL, bool ZROWS>
+__device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int k_steps,
                                          int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][2])
 {
+    using G = Geom<AT>;
+    constexpr int EPT = G::EPT, NP = G::NP;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int s_k4 = (tid % TPR) * 4;
+    const int s_k = (tid % G::TPR) * EPT;  // first k of this thread's 16-B piece
 
-    float4 ra[NP];
+    // Global loads are issued raw (clamped address, no select on the result): the validity select
+    // is applied one stage later, at the split -- a select next to the load would make hipcc wait
+    // for the load inside the issuing block (measured: 460 -> 640 us).
+    float ra[NP][EPT];
     auto load_a_pass = [&](int i, int k0) {
-        const int gk = k0 + s_k4;
-        {
-            if constexpr (AVEC) {
-                bool in = true;
-                if constexpr (!KFULL) in = gk < K;  // K % 4 == 0: a float4 is all in or all out
-                if constexpr (ZROWS) in = in && avalid[i];
-                const float4 v = *reinterpret_cast<const float4 *>(arow[i] + ((KFULL || gk < K) ? gk : 0));
-                ra[i] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                float e[4];
+        const int gk = k0 + s_k;
+        if constexpr (AVEC) {
+            load16<AT>(arow[i] + ((KFULL || gk < K) ? gk : 0), ra[i]);
+        } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const bool ink = gk + c < K;
-                    const float v = arow[i][ink ? gk + c : 0];
-                    e[c] = (ink && (!ZROWS || avalid[i])) ? v : 0.0f;
-                }
-                ra[i] = make_float4(e[0], e[1], e[2], e[3]);
-            }
+            for (int c = 0; c < EPT; ++c) ra[i][c] = elem_to_float(arow[i][(gk + c < K) ? gk + c : 0]);
         }
     };
     auto load_a = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) load_a_pass(i, k0);
     };
-    auto store_a_pass = [&](int buf, int i) {
+    // split pass i (rows of the stage that starts at k0) into the two bf16 planes of buffer `buf`
+    auto store_a_pass = [&](int buf, int i, int k0) {
         char *hi_plane = lds + buf * (2 * BM * ROWB);
         char *lo_plane = hi_plane + BM * ROWB;
-        {
-            const int row = stage_row(i);
-            const int off = a_lds_off(row, s_k4 >> 3) + (s_k4 & 4) * 2;
-            bf16x4 hi, lo;
-#if defined(GGCN_LAB_NO_SPLIT)
-            hi[0] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(ra[i].x) >> 16));
-            hi[1] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(ra[i].y) >> 16));
-            hi[2] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(ra[i].z) >> 16));
-            hi[3] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(ra[i].w) >> 16));
-            lo = hi;
-#else
-            hi[0] = (__bf16)ra[i].x; hi[1] = (__bf16)ra[i].y; hi[2] = (__bf16)ra[i].z; hi[3] = (__bf16)ra[i].w;
-            lo[0] = (__bf16)(ra[i].x - (float)hi[0]);
-            lo[1] = (__bf16)(ra[i].y - (float)hi[1]);
-            lo[2] = (__bf16)(ra[i].z - (float)hi[2]);
-            lo[3] = (__bf16)(ra[i].w - (float)hi[3]);
-#endif
-#if defined(GGCN_LAB_NO_DSWRITE)
-            asm volatile("" ::"v"(hi), "v"(lo), "v"(off));
-            (void)hi_plane; (void)lo_plane;
-#else
-            *reinterpret_cast<bf16x4 *>(hi_plane + off) = hi;
-            *reinterpret_cast<bf16x4 *>(lo_plane + off) = lo;
-#endif
+        const int row = stage_row<AT>(i);
+        const int off = a_lds_off(row, s_k >> 3) + (s_k & 4) * 2;
+        const int gk = k0 + s_k;
+        __bf16 hi[EPT], lo[EPT];
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) {
+            float x = ra[i][c];
+            if constexpr (!KFULL || ZROWS) {
+                bool in = true;
+                if constexpr (!KFULL) in = gk + c < K;
+                if constexpr (ZROWS) in = in && avalid[i];
+                x = in ? x : 0.0f;
+            }
+            hi[c] = (__bf16)x;
+            lo[c] = (__bf16)(x - (float)hi[c]);
+        }
+        if constexpr (EPT == 4) {
+            *reinterpret_cast<bf16x4 *>(hi_plane + off) = bf16x4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<bf16x4 *>(lo_plane + off) = bf16x4{lo[0], lo[1], lo[2], lo[3]};
+        } else {
+            *reinterpret_cast<bf16x8 *>(hi_plane + off) = bf16x8{hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+            *reinterpret_cast<bf16x8 *>(lo_plane + off) = bf16x8{lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
         }
     };
 
@@ -183,7 +202,7 @@ __device__ __forceinline__ void mainloop(const float *const (&arow)[NP], const b
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    static_assert(BK == 32 && NP == 4, "the interleaved stage below is written for BK = 32");
+    static_assert(BK == 32 && NP <= 4, "the interleaved stage below is written for BK = 32");
     bf16x8 b0[2][2], b1[2][2];
     const int stages = (K + BK - 1) / BK;
     const int last_k0 = (stages - 1) * BK;
@@ -192,7 +211,7 @@ __device__ __forceinline__ void mainloop(const float *const (&arow)[NP], const b
     load_a(0);
     load_b(0, b0);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) store_a_pass(0, p);
+    for (int p = 0; p < NP; ++p) store_a_pass(0, p, 0);
     load_a(BK < last_k0 ? BK : last_k0);
     __syncthreads();
 
@@ -204,6 +223,7 @@ __device__ __forceinline__ void mainloop(const float *const (&arow)[NP], const b
     // B fragments one k-step ahead; issue order = consumption order (vmcnt retires in order).
     auto stage = [&](int st, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
+        const int k_next1 = (st + 1) * BK < last_k0 ? (st + 1) * BK : last_k0;
         const int k_next2 = (st + 2) * BK;
         const int ka = k_next2 < last_k0 ? k_next2 : last_k0;  // past the end: harmless re-read
         load_b(st * KS + 1, b1);
@@ -211,8 +231,10 @@ __device__ __forceinline__ void mainloop(const float *const (&arow)[NP], const b
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             mma_block(buf, 0, i, b0);
-            store_a_pass(buf ^ 1, i);   // rows of stage st+1 -> the other buffer
-            load_a_pass(i, ka);         // rows of stage st+2
+            if (i < NP) {
+                store_a_pass(buf ^ 1, i, k_next1);  // rows of stage st+1 -> the other buffer
+                load_a_pass(i, ka);         // rows of stage st+2
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         load_b(st * KS + 2, b0);

@@ -93,6 +93,25 @@ int ggcn_aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const in
                      out, ldo, pool_a, pool_b, as_stream(stream));
 }
 
+int ggcn_linear_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M, int K, int F,
+                  ggcn_stream_t stream)
+{
+    if (!X || !Y) return fail(GGCN_EINVAL, "ggcn_linear_h: null pointer");
+    if (M <= 0 || K <= 0 || F <= 0)
+        return fail(GGCN_EINVAL, "ggcn_linear_h: M=%lld K=%d F=%d must be positive", (long long)M, K, F);
+    if (ldx < K || ldy < F) return fail(GGCN_EINVAL, "ggcn_linear_h: leading dimension too small");
+    return linear_bf16x3_h(X, ldx, wpack, Y, ldy, M, K, F, as_stream(stream));
+}
+
+int ggcn_aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
+                     const float *vals, const float *bias, int B, int T, int F, const float *store_gate,
+                     const float *pool_gate_a, const float *pool_gate_b, void *out, int64_t ldo,
+                     float *pool_a, float *pool_b, ggcn_stream_t stream)
+{
+    return aggregate_h(Hd, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a, pool_gate_b, out,
+                       ldo, pool_a, pool_b, as_stream(stream));
+}
+
 size_t ggcn_overlap_workspace_bytes(int B) { return overlap_workspace_bytes(B); }
 
 int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,

@@ -40,6 +40,12 @@ int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, hipStrea
 int linear_bf16x3(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy,
                   int64_t M, int K, int F, hipStream_t st);
 
+int linear_bf16x3_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M, int K,
+                    int F, hipStream_t st);
+int aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx, const float *vals,
+                const float *bias, int B, int T, int F, const float *store_gate, const float *pool_gate_a,
+                const float *pool_gate_b, void *out, int64_t ldo, float *pool_a, float *pool_b, hipStream_t st);
+
 int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
               const float *vals, const float *bias, int B, int T, int F, const float *store_gate,
               const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,

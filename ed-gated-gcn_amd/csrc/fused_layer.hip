@@ -63,11 +63,12 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
     const int nt0 = n_wgi * (BN / NT) + wn * 2;
 
     // tile row 32*slot + r  <->  node r of graph g0+slot
+    constexpr int NP = Geom<float>::NP;
     const float *arow[NP];
     bool avalid[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int row = stage_row(i);
+        const int row = stage_row<float>(i);
         const int g = g0 + (row >> 5), r = row & 31;
         avalid[i] = (g < B) && (FULLT || r < T);
         const int64_t node = avalid[i] ? (int64_t)g * T + r : 0;  // clamped, zeroed by the select
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
     }
 
     f32x16 acc[4][2];
-    mainloop<AVEC, KFULL, true>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);
+    mainloop<float, AVEC, KFULL, true>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);
 
     const int c = lane & 31, h = lane >> 5;
 

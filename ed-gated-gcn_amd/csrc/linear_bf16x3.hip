@@ -41,10 +41,14 @@ __global__ __launch_bounds__(128) void weight_pack_kernel(const float *__restric
     pack[(((int64_t)n_tile * k_steps + k_step) * 2 + plane) * 64 + lane] = v;
 }
 
-template <bool AVEC, bool KFULL>
+__device__ __forceinline__ void store_elem(float *p, float v) { *p = v; }
+__device__ __forceinline__ void store_elem(__half *p, float v) { *p = __float2half_rn(v); }
+
+// ET: element type of X and Y (float, or __half with fp32 accumulation)
+template <typename ET, bool AVEC, bool KFULL>
 __global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
-    const float *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
-    float *__restrict__ Y, int64_t ldy, int64_t M, int K, int F, int m_tiles, int n_wg, int k_steps)
+    const ET *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
+    ET *__restrict__ Y, int64_t ldy, int64_t M, int K, int F, int m_tiles, int n_wg, int k_steps)
 {
     __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
     int m_tile, n_wgi;
@@ -58,17 +62,18 @@ __global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
     const int nt0 = n_wgi * (BN / NT) + wn * 2;  // this wavefront's first 32-column tile
 
     // rows past M are clamped to row M-1: a row of A only feeds the same row of Y, never stored
-    const float *arow[NP];
+    constexpr int NP = Geom<ET>::NP;
+    const ET *arow[NP];
     bool avalid[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        int64_t gm = m0 + stage_row(i);
+        int64_t gm = m0 + stage_row<ET>(i);
         gm = gm < M ? gm : M - 1;
         arow[i] = X + gm * ldx;
         avalid[i] = true;
     }
     f32x16 acc[4][2];
-    mainloop<AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);
+    mainloop<ET, AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);
 
 #ifndef GGCN_LAB_NO_STORE
     const bool full_rows = m0 + BM <= M;  // workgroup-uniform: the row guard only exists in the last tile
@@ -79,14 +84,15 @@ __global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t gmb = m0 + i * 32 + 4 * (lane >> 5);
-            float *yb = Y + gmb * ldy + gn;
+            ET *yb = Y + gmb * ldy + gn;
             if (full_rows) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yb[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) store_elem(yb + (int64_t)((r & 3) + 8 * (r >> 2)) * ldy, acc[i][j][r]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (gmb + (r & 3) + 8 * (r >> 2) < M) yb[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = acc[i][j][r];
+                    if (gmb + (r & 3) + 8 * (r >> 2) < M)
+                        store_elem(yb + (int64_t)((r & 3) + 8 * (r >> 2)) * ldy, acc[i][j][r]);
             }
         }
     }
@@ -95,8 +101,33 @@ __global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-    if (M < 0) Y[0] = 0.f;
+    if (M < 0) store_elem(Y, 0.f);
 #endif
+}
+
+template <typename ET>
+int launch_linear(const ET *X, int64_t ldx, const void *wpack, ET *Y, int64_t ldy, int64_t M, int K, int F,
+                  hipStream_t st)
+{
+    if (!wpack) return fail(GGCN_EINVAL, "ggcn_linear(bf16x3): wpack is NULL (call ggcn_weight_pack first)");
+    if (!aligned16(wpack)) return fail(GGCN_EINVAL, "ggcn_linear(bf16x3): wpack must be 16-byte aligned");
+    constexpr int EPT = Geom<ET>::EPT;
+    const bool avec = (K % EPT == 0) && (ldx % EPT == 0) && aligned16(X);
+    const bool kfull = (K % BK == 0);
+    const int k_steps = round_up(K, BK) / KSTEP;
+    const int64_t m_tiles = (M + BM - 1) / BM;
+    const int n_wg = (F + BN - 1) / BN;
+    const int64_t grid = grid_for(m_tiles, n_wg);
+    if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_linear(bf16x3): M too large");
+    const char *wp = static_cast<const char *>(wpack);
+#define GGCN_LAUNCH(AV, KF)                                                                                     \
+    hipLaunchKernelGGL((linear_bf16x3_kernel<ET, AV, KF>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, \
+                       wp, Y, ldy, M, K, F, (int)m_tiles, n_wg, k_steps)
+    if (avec && kfull) GGCN_LAUNCH(true, true);
+    else if (avec) GGCN_LAUNCH(true, false);
+    else GGCN_LAUNCH(false, false);
+#undef GGCN_LAUNCH
+    return check_launch("ggcn_linear(bf16x3)");
 }
 
 }  // namespace
@@ -125,24 +156,13 @@ int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, hipStrea
 int linear_bf16x3(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy, int64_t M,
                   int K, int F, hipStream_t st)
 {
-    if (!wpack) return fail(GGCN_EINVAL, "ggcn_linear(bf16x3): wpack is NULL (call ggcn_weight_pack first)");
-    if (!aligned16(wpack)) return fail(GGCN_EINVAL, "ggcn_linear(bf16x3): wpack must be 16-byte aligned");
-    const bool avec = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
-    const bool kfull = (K % BK == 0);
-    const int k_steps = round_up(K, BK) / KSTEP;
-    const int64_t m_tiles = (M + BM - 1) / BM;
-    const int n_wg = (F + BN - 1) / BN;
-    const int64_t grid = grid_for(m_tiles, n_wg);
-    if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_linear(bf16x3): M too large");
-    const char *wp = static_cast<const char *>(wpack);
-#define GGCN_LAUNCH(AV, KF)                                                                                 \
-    hipLaunchKernelGGL((linear_bf16x3_kernel<AV, KF>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, \
-                       wp, Y, ldy, M, K, F, (int)m_tiles, n_wg, k_steps)
-    if (avec && kfull) GGCN_LAUNCH(true, true);
-    else if (avec) GGCN_LAUNCH(true, false);
-    else GGCN_LAUNCH(false, false);
-#undef GGCN_LAUNCH
-    return check_launch("ggcn_linear(bf16x3)");
+    return launch_linear<float>(X, ldx, wpack, Y, ldy, M, K, F, st);
+}
+
+int linear_bf16x3_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M,
+                    int K, int F, hipStream_t st)
+{
+    return launch_linear<__half>(static_cast<const __half *>(X), ldx, wpack, static_cast<__half *>(Y), ldy, M, K, F, st);
 }
 
 }  // namespace ggcn

@@ -20,15 +20,14 @@ from . import _capi
 from .csr import BatchedCSR
 
 
-def _require_gpu_f32(name, t):
+def _require_gpu_f32(name, t, allow_half=False):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)
     if not t.is_cuda:
         raise RuntimeError("%s is on %s: this layer only runs on the GPU (libggcn_hip.so); "
                            "there is no CPU fallback" % (name, t.device))
-    if t.dtype != torch.float32:
-        # the reference raises a dtype-mismatch RuntimeError for half inputs too
-        raise RuntimeError("%s must be float32, got %s" % (name, t.dtype))
+    if t.dtype != torch.float32 and not (allow_half and t.dtype == torch.float16):
+        raise RuntimeError("%s must be float32%s, got %s" % (name, " or float16" if allow_half else "", t.dtype))
 
 
 class GraphConvolution(nn.Module):
@@ -86,7 +85,11 @@ class GraphConvolution(nn.Module):
         return BatchedCSR.from_dense(adj)  # gcn.py:33 accepts any real dtype
 
     def _check(self, text):
-        _require_gpu_f32("text", text)
+        # float16 features (BASELINE configs[3]) are an extension: the reference itself raises a
+        # dtype mismatch for half inputs.  Weights, bias, gates stay float32.
+        _require_gpu_f32("text", text, allow_half=True)
+        if text.dtype == torch.float16 and self.precision != "bf16x3":
+            raise RuntimeError("float16 features need precision='bf16x3' (the exact-fp32 linear is fp32 only)")
         if text.dim() != 3 or text.shape[2] != self.in_features:
             raise RuntimeError("text must be [B,T,%d], got %s" % (self.in_features, tuple(text.shape)))
         if self.weight.device != text.device:
@@ -105,7 +108,13 @@ class GraphConvolution(nn.Module):
         dev = x2d.device
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
-            y = torch.empty(x2d.shape[0], self.out_features, dtype=torch.float32, device=dev)
+            y = torch.empty(x2d.shape[0], self.out_features, dtype=x2d.dtype, device=dev)
+            if x2d.dtype == torch.float16:
+                pack = self._packed_weight(lib, st)
+                _capi.check(lib.ggcn_linear_h(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack), _capi.ptr(y),
+                                              y.stride(0), x2d.shape[0], self.in_features, self.out_features, st),
+                            "ggcn_linear_h")
+                return y
             w = self.weight.detach()
             if not w.is_contiguous():
                 w = w.contiguous()
@@ -138,12 +147,13 @@ class GraphConvolution(nn.Module):
                 if tuple(g.shape) != (B, F) or not g.is_contiguous():
                     raise RuntimeError("%s must be a contiguous [B,F]=[%d,%d] tensor, got %s"
                                        % (name, B, F, tuple(g.shape)))
+        half = text.dtype == torch.float16
         use_fused = (self.fused and self.precision == "bf16x3" and csr.rowmask is not None
-                     and csr.vals is None)
+                     and csr.vals is None and not half)
         hidden = None if use_fused else self.linear(x2d)
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
-            out = torch.empty(B * T, F, dtype=torch.float32, device=dev) if want_out else None
+            out = torch.empty(B * T, F, dtype=text.dtype, device=dev) if want_out else None
             pa = torch.empty(B, F, dtype=torch.float32, device=dev) if want_pool_a else None
             pb = torch.empty(B, F, dtype=torch.float32, device=dev) if want_pool_b else None
             bias = None if self.bias is None else self.bias.detach()
@@ -155,7 +165,8 @@ class GraphConvolution(nn.Module):
                                                  _capi.ptr(pool_gate_a), _capi.ptr(pool_gate_b), _capi.ptr(out),
                                                  F, _capi.ptr(pa), _capi.ptr(pb), st), "ggcn_layer_fused")
                 return (None if out is None else out.view(B, T, F)), pa, pb
-            _capi.check(lib.ggcn_aggregate(_capi.ptr(hidden), hidden.stride(0), _capi.ptr(csr.rowptr),
+            agg = lib.ggcn_aggregate_h if half else lib.ggcn_aggregate
+            _capi.check(agg(_capi.ptr(hidden), hidden.stride(0), _capi.ptr(csr.rowptr),
                                            _capi.ptr(csr.colidx), _capi.ptr(csr.vals), _capi.ptr(bias),
                                            B, T, F, _capi.ptr(store_gate), _capi.ptr(pool_gate_a),
                                            _capi.ptr(pool_gate_b), _capi.ptr(out), F, _capi.ptr(pa),

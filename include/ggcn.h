@@ -124,6 +124,21 @@ int ggcn_aggregate(const float *Hd, int64_t ldh,
                    float *out, int64_t ldo, float *pool_a, float *pool_b,
                    ggcn_stream_t stream);
 
+/* ---- fp16 features (BASELINE configs[3]: 512-token graphs, hidden 1024) ------------------
+ * Same operations with X / hidden / out stored as IEEE half and fp32 accumulation; weights
+ * (wpack), bias, gates and pooled outputs stay fp32.  The reference cannot run half inputs
+ * (models/gcn.py:33-34 raise a dtype mismatch); parity is against the fp32 reference
+ * on fp16-rounded inputs.  An fp16 value splits exactly into two bf16 terms, so the linear uses
+ * the same three-product scheme as GGCN_PREC_BF16X3. */
+int ggcn_linear_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy,
+                  int64_t M, int K, int F, ggcn_stream_t stream);
+int ggcn_aggregate_h(const void *Hd, int64_t ldh,
+                     const int32_t *rowptr, const int32_t *colidx, const float *vals,
+                     const float *bias, int B, int T, int F,
+                     const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
+                     void *out, int64_t ldo, float *pool_a, float *pool_b,
+                     ggcn_stream_t stream);
+
 /* ---- one whole gated layer in one launch (graphs of <= 32 nodes, binary adjacency) ----
  * Replaces models/gcn.py:34-45 + models/bert_amir5.py:627-640 without materialising
  * `hidden`: the bf16x3 linear's accumulator tile (one graph x 32 features) is multiplied by

@@ -239,7 +239,7 @@ def test_errors_are_loud(pkg, dev):
     x = torch.zeros(2, 4, 8, device=dev)
     with pytest.raises(RuntimeError):
         with torch.no_grad():
-            m(x.half(), torch.zeros(2, 4, 4, device=dev))      # reference: dtype mismatch (F7)
+            m(x.double(), torch.zeros(2, 4, 4, device=dev))    # only float32 / float16 features
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             m(x, torch.zeros(2, 5, 5, device=dev))             # shape mismatch
@@ -341,3 +341,29 @@ def test_config4_long_document_sample(pkg, dev):
         with torch.no_grad():
             out = m(torch.from_numpy(x).to(dev), torch.from_numpy(adj).to(dev))
         np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=TOL[precision])
+
+
+@pytest.mark.parametrize("B,T,H", [(4, 512, 1024), (3, 100, 200), (5, 31, 72), (2, 9, 13)])
+def test_fp16_features_config4(pkg, dev, B, T, H):
+    """BASELINE.json configs[3]: fp16 features, fp32 accumulation.  The reference cannot run half
+    inputs, so the oracle is its fp32 forward on the fp16-ROUNDED inputs; the HIP path
+    additionally rounds `hidden` and the output to fp16 -> atol 2e-3."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(B * T)
+    adj = synth.dependency_batch(B, T, min(6.0, T), seed=21)
+    x16 = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32)).half()
+    g = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32)))
+    w, b = synth.layer_params(H, H, seed=5)
+    ref = ref_dense.graph_convolution(x16.float(), torch.from_numpy(adj), torch.from_numpy(w), torch.from_numpy(b))
+    ref_gated = (ref * g[:, None, :])
+    m = _layer(pkg, dev, w, b, "bf16x3")
+    with torch.no_grad():
+        out, pa, _ = m.forward_gated(x16.to(dev), torch.from_numpy(adj).to(dev), store_gate=g.to(dev),
+                                     pool_gate_a=g.to(dev), want_pool_a=True)
+    assert out.dtype == torch.float16 and pa.dtype == torch.float32
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref_gated.numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(pa.cpu().numpy(), ref_gated.max(dim=1)[0].numpy(), rtol=0, atol=2e-3)
+    mf = _layer(pkg, dev, w, b, "fp32")
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            mf(x16.to(dev), torch.from_numpy(adj).to(dev))

@@ -61,7 +61,8 @@ def time_variants(what, names):
         path = os.path.join(LAB, "libggcn_%s.so" % n) if n != "main" else pkg.lib_path()
         lib = ctypes.CDLL(path)
         for fn, (res, args) in _capi.PROTOTYPES.items():
-            getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
+            if hasattr(lib, fn):
+                getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
         pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H), dtype=torch.uint8, device=dev)
         assert lib.ggcn_weight_pack(_capi.ptr(w), H, H, H, _capi.ptr(pack), None) == 0
         libs[n] = (lib, pack)
