@@ -85,6 +85,21 @@ struct Seg<__half, 1> {
     static __device__ __forceinline__ void store(__half *p, const float (&v)[1]) { *p = __float2half_rn(v[0]); }
 };
 
+template <int VEC>
+__device__ __forceinline__ void load_f32(const float *p, float (&v)[VEC])
+{
+    if constexpr (VEC % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const float4 t = reinterpret_cast<const float4 *>(p)[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] = p[k];
+    }
+}
+
 // grid.x = B * n_slabs ; block = 256.  slab = 64*VEC columns.  E = feature element type
 // (float, or __half with fp32 accumulation: BASELINE configs[3]); bias, gates, pools are fp32.
 template <typename E, int VEC, bool HAS_VALS>
@@ -112,15 +127,12 @@ __global__ __launch_bounds__(256) void aggregate_rows(
         vb[k] = 0.0f; vsg[k] = 1.0f; vga[k] = 1.0f; vgb[k] = 1.0f;
         pa[k] = -INFINITY; pb[k] = -INFINITY;
     }
-    if (live) {
+    if (live) {  // fp32 side inputs of this lane's columns: 16-B loads when VEC allows
         const int64_t g = (int64_t)b * F + col;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {  // contiguous: the compiler merges these into 16-B loads
-            if (bias) vb[k] = bias[col + k];
-            if (store_gate) vsg[k] = store_gate[g + k];
-            if (pool_gate_a) vga[k] = pool_gate_a[g + k];
-            if (pool_gate_b) vgb[k] = pool_gate_b[g + k];
-        }
+        if (bias) load_f32<VEC>(bias + col, vb);
+        if (store_gate) load_f32<VEC>(store_gate + g, vsg);
+        if (pool_gate_a) load_f32<VEC>(pool_gate_a + g, vga);
+        if (pool_gate_b) load_f32<VEC>(pool_gate_b + g, vgb);
     }
 
     const E *hcol = Hd + col;
@@ -229,6 +241,11 @@ int launch(const E *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colid
     return check_launch("ggcn_aggregate");
 }
 
+bool side_aligned(const float *bias, const float *sg, const float *ga, const float *gb)
+{
+    return (!bias || aligned16(bias)) && (!sg || aligned16(sg)) && (!ga || aligned16(ga)) && (!gb || aligned16(gb));
+}
+
 int check_args(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx, int B, int T, int F,
                const void *out, int64_t ldo, const float *pool_a, const float *pool_b)
 {
@@ -251,7 +268,8 @@ int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t
               float *pool_a, float *pool_b, hipStream_t st)
 {
     if (int rc = check_args(Hd, ldh, rowptr, colidx, B, T, F, out, ldo, pool_a, pool_b)) return rc;
-    const bool vec = (F % 4 == 0) && (ldh % 4 == 0) && aligned16(Hd) && (!out || ((ldo % 4 == 0) && aligned16(out)));
+    const bool vec = (F % 4 == 0) && (ldh % 4 == 0) && aligned16(Hd) && (!out || ((ldo % 4 == 0) && aligned16(out))) &&
+                     side_aligned(bias, store_gate, pool_gate_a, pool_gate_b);
     if (vec)
         return launch<float, 4>(Hd, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
                                 pool_gate_b, out, ldo, pool_a, pool_b, st);
@@ -267,7 +285,8 @@ int aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_
     if (int rc = check_args(Hd, ldh, rowptr, colidx, B, T, F, out, ldo, pool_a, pool_b)) return rc;
     const __half *h = static_cast<const __half *>(Hd);
     __half *o = static_cast<__half *>(out);
-    const bool vec = (F % 8 == 0) && (ldh % 8 == 0) && aligned16(Hd) && (!out || ((ldo % 8 == 0) && aligned16(out)));
+    const bool vec = (F % 8 == 0) && (ldh % 8 == 0) && aligned16(Hd) && (!out || ((ldo % 8 == 0) && aligned16(out))) &&
+                     side_aligned(bias, store_gate, pool_gate_a, pool_gate_b);
     if (vec)
         return launch<__half, 8>(h, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
                                  pool_gate_b, o, ldo, pool_a, pool_b, st);

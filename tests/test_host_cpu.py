@@ -127,3 +127,31 @@ def test_from_arrays_validates():
     big = synth.dependency_batch(1, 40, 3.0)
     rp, ci, _ = synth.csr_from_dense_host(big)
     assert BatchedCSR.from_arrays(rp, ci, 1, 40, "cpu").rowmask is None   # T > 32: no masks
+
+
+def test_graph_batcher_matches_dense_slice():
+    """per-sample cache + collate == CSR of the reference's adj[:, :T, :T]."""
+    from ed_gated_gcn_amd.batcher import GraphBatcher
+    ORI_ML = 31                                           # constant.py:237
+    lens = np.array([9, 31, 17, 24, 5])
+    dense = synth.dependency_batch(5, ORI_ML, 3.0, seed=2, lengths=lens)   # identity on padding (graph.py:66)
+    bt = GraphBatcher()
+    for i in range(5):
+        bt.add("s%d" % i, dense[i])
+    ids = ["s3", "s0", "s4"]
+    T = int(lens[[3, 0, 4]].max())                        # batch max length (bert_amir5.py:581)
+    got = bt.collate(ids, T, "cpu")
+    sl = dense[[3, 0, 4]][:, :T, :T]                      # bert_amir5.py:589
+    rp, ci, _ = synth.csr_from_dense_host(sl)
+    assert np.array_equal(got.rowptr.numpy(), rp) and np.array_equal(got.colidx.numpy(), ci)
+    assert got.vals is None and got.B == 3 and got.T == T
+    want_mask = (sl.reshape(-1, T).astype(np.uint32) << np.arange(T, dtype=np.uint32)).sum(axis=1)
+    assert np.array_equal(got.rowmask.numpy().view(np.uint32), want_mask)
+    # weighted sample keeps its values, the others read as ones
+    w = dense[1].astype(np.float32) * 0.5
+    bt.add("w", w)
+    mix = bt.collate(["w", "s1"], ORI_ML, "cpu")
+    rp2, ci2, v2 = synth.csr_from_dense_host(np.stack([w, dense[1].astype(np.float32)]))
+    assert np.array_equal(mix.colidx.numpy(), ci2) and np.allclose(mix.vals.numpy(), v2)
+    with pytest.raises(ValueError):
+        bt.collate(["s0"], 40, "cpu")
