@@ -28,6 +28,9 @@ PROTOTYPES = {
     "ggcn_linear": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "ggcn_weight_pack_t": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "ggcn_inv_denominators": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "ggcn_aggregate_t": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "ggcn_linear_h": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "ggcn_aggregate_h": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                  c_vp, c_i64, c_vp, c_vp, c_vp]),

@@ -20,11 +20,15 @@ class BatchedCSR:
     """rowptr int32[N+1], colidx int32[cap], vals fp32[cap] or None (binary adjacency),
     rowmask uint32-as-int32[N] or None (T <= 32: bit j of word i = edge i<-j), on one GPU."""
 
-    __slots__ = ("rowptr", "colidx", "vals", "rowmask", "B", "T", "nnz")
+    __slots__ = ("rowptr", "colidx", "vals", "rowmask", "B", "T", "nnz", "_dense", "_host", "_t", "_inv")
 
     def __init__(self, rowptr, colidx, vals, B, T, nnz=None, rowmask=None):
         self.rowptr, self.colidx, self.vals, self.rowmask = rowptr, colidx, vals, rowmask
         self.B, self.T, self.nnz = int(B), int(T), nnz
+        self._dense = None   # the dense tensor this CSR was built from (kept for transposed())
+        self._host = None    # (rowptr, colidx, vals) numpy arrays when built on the host
+        self._t = None       # cached CSR of the transposed adjacency (backward pass)
+        self._inv = None     # cached 1/(rowsum+1) per node
 
     @property
     def device(self):
@@ -70,7 +74,9 @@ class BatchedCSR:
         _capi.check(rc, "ggcn_csr_from_dense")
         if binary is None and not (int(flags.item()) & _capi.FLAG_WEIGHTED):
             vals = None
-        return cls(rowptr, colidx, vals, B, T, rowmask=rowmask)
+        out = cls(rowptr, colidx, vals, B, T, rowmask=rowmask)
+        out._dense = (adj, vals is None)
+        return out
 
     @classmethod
     def from_arrays(cls, rowptr, colidx, B, T, device, vals=None):
@@ -95,5 +101,41 @@ class BatchedCSR:
             m = np.zeros(B * T, dtype=np.uint32)
             np.bitwise_or.at(m, rows, (np.uint32(1) << (colidx.astype(np.int64) % T).astype(np.uint32)))
             mask = torch.from_numpy(m.view(np.int32)).to(device)
-        return cls(torch.from_numpy(rowptr).to(device), torch.from_numpy(colidx).to(device), v, B, T,
-                   nnz=int(colidx.shape[0]), rowmask=mask)
+        out = cls(torch.from_numpy(rowptr).to(device), torch.from_numpy(colidx).to(device), v, B, T,
+                  nnz=int(colidx.shape[0]), rowmask=mask)
+        out._host = (rowptr, colidx, None if v is None else np.ascontiguousarray(vals, dtype=np.float32))
+        return out
+
+    def transposed(self):
+        """CSR of the transposed adjacency (rows = source nodes), cached: the backward pass applies
+        A^T.  Built from the dense tensor by swapping its strides, or on the host from the arrays."""
+        if self._t is None:
+            if self._dense is not None:
+                adj, binary = self._dense
+                self._t = BatchedCSR.from_dense(adj.transpose(1, 2), binary=binary)
+            elif self._host is not None:
+                import numpy as np
+                import scipy.sparse as sp
+                rowptr, colidx, vals = self._host
+                n = self.B * self.T
+                data = np.ones(len(colidx), dtype=np.float32) if vals is None else vals
+                mt = sp.csr_matrix((data, colidx, rowptr), shape=(n, n)).T.tocsr()
+                mt.sort_indices()
+                self._t = BatchedCSR.from_arrays(mt.indptr, mt.indices, self.B, self.T, self.device,
+                                                 vals=None if vals is None else mt.data)
+            else:
+                raise RuntimeError("this BatchedCSR was assembled by hand: no source to transpose from")
+            self._t._t = self
+        return self._t
+
+    def inv_denominators(self):
+        """fp32 [N]: 1 / (rowsum(adj) + 1) (``models/gcn.py:35``), cached."""
+        if self._inv is None:
+            lib = _capi.load_library()
+            dev = self.device
+            inv = torch.empty(self.n_nodes, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _capi.check(lib.ggcn_inv_denominators(_capi.ptr(self.rowptr), _capi.ptr(self.vals), self.n_nodes,
+                                                      _capi.ptr(inv), _capi.stream_of(dev)), "ggcn_inv_denominators")
+            self._inv = inv
+        return self._inv

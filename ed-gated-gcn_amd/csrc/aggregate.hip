@@ -102,10 +102,14 @@ __device__ __forceinline__ void load_f32(const float *p, float (&v)[VEC])
 
 // grid.x = B * n_slabs ; block = 256.  slab = 64*VEC columns.  E = feature element type
 // (float, or __half with fp32 accumulation: BASELINE configs[3]); bias, gates, pools are fp32.
-template <typename E, int VEC, bool HAS_VALS>
+// NORM = true: the forward (divide by rowsum+1, bias, gates, pools).  NORM = false: the plain
+// weighted sum out[i] = sum_e vals[e] * src_scale[colidx[e]] * Hd[colidx[e]] used by the backward
+// pass (the transposed adjacency applied to D.dY: src_scale = 1/(rowsum+1) of the SOURCE row).
+template <typename E, int VEC, bool HAS_VALS, bool NORM = true>
 __global__ __launch_bounds__(256) void aggregate_rows(
     const E *__restrict__ Hd, int64_t ldh, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+    const float *__restrict__ src_scale,
     const float *__restrict__ bias, int T, int F, int n_slabs,
     const float *__restrict__ store_gate, const float *__restrict__ pool_gate_a,
     const float *__restrict__ pool_gate_b, E *__restrict__ out, int64_t ldo,
@@ -160,11 +164,17 @@ __global__ __launch_bounds__(256) void aggregate_rows(
                 Seg<E, VEC>::load(hcol + (int64_t)c2 * ldh, h2);
                 Seg<E, VEC>::load(hcol + (int64_t)c3 * ldh, h3);
             }
-            if constexpr (HAS_VALS) {
-                const float w0 = vals[e];
-                const float w1 = v1 ? vals[e + 1] : 0.0f;
-                const float w2 = v2 ? vals[e + 2] : 0.0f;
-                const float w3 = v3 ? vals[e + 3] : 0.0f;
+            if constexpr (HAS_VALS || !NORM) {
+                float w0 = HAS_VALS ? vals[e] : 1.0f;
+                float w1 = v1 ? (HAS_VALS ? vals[e + 1] : 1.0f) : 0.0f;
+                float w2 = v2 ? (HAS_VALS ? vals[e + 2] : 1.0f) : 0.0f;
+                float w3 = v3 ? (HAS_VALS ? vals[e + 3] : 1.0f) : 0.0f;
+                if constexpr (!NORM) {
+                    w0 *= src_scale[c0];
+                    w1 *= src_scale[c1];
+                    w2 *= src_scale[c2];
+                    w3 *= src_scale[c3];
+                }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {  // a masked-out neighbour must not contribute 0*inf
                     acc[k] = fmaf(w0, h0[k], acc[k]);
@@ -186,12 +196,12 @@ __global__ __launch_bounds__(256) void aggregate_rows(
                 }
             }
         }
-        const float denom = (HAS_VALS ? wsum : (float)(end - beg)) + 1.0f;  // gcn.py:35
+        const float denom = NORM ? (HAS_VALS ? wsum : (float)(end - beg)) + 1.0f : 1.0f;  // gcn.py:35
         if (live) {
             float y[VEC], o[VEC];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                y[k] = acc[k] / denom + vb[k];  // gcn.py:41,43; IEEE division like torch's `/`
+                y[k] = NORM ? acc[k] / denom + vb[k] : acc[k];  // gcn.py:41,43; IEEE division like torch's `/`
                 o[k] = y[k] * vsg[k];
                 pa[k] = fmaxf(pa[k], y[k] * vga[k]);
                 pb[k] = fmaxf(pb[k], y[k] * vgb[k]);
@@ -234,11 +244,46 @@ int launch(const E *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colid
     if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_aggregate: grid too large");
     if (vals)
         hipLaunchKernelGGL((aggregate_rows<E, VEC, true>), dim3((unsigned)blocks), dim3(256), 0, st, Hd, ldh,
-                           rowptr, colidx, vals, bias, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb);
+                           rowptr, colidx, vals, nullptr, bias, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb);
     else
         hipLaunchKernelGGL((aggregate_rows<E, VEC, false>), dim3((unsigned)blocks), dim3(256), 0, st, Hd, ldh,
-                           rowptr, colidx, vals, bias, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb);
+                           rowptr, colidx, vals, nullptr, bias, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb);
     return check_launch("ggcn_aggregate");
+}
+
+template <int VEC>
+int launch_t(const float *G, int64_t ldg, const int32_t *rowptr, const int32_t *colidx, const float *vals,
+             const float *src_scale, int B, int T, int F, float *out, int64_t ldo, hipStream_t st)
+{
+    const int slab = kWave * VEC;
+    const int n_slabs = (F + slab - 1) / slab;
+    const int64_t blocks = (int64_t)B * n_slabs;
+    if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_aggregate_t: grid too large");
+    if (vals)
+        hipLaunchKernelGGL((aggregate_rows<float, VEC, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, G,
+                           ldg, rowptr, colidx, vals, src_scale, nullptr, T, F, n_slabs, nullptr, nullptr, nullptr,
+                           out, ldo, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((aggregate_rows<float, VEC, false, false>), dim3((unsigned)blocks), dim3(256), 0, st, G,
+                           ldg, rowptr, colidx, vals, src_scale, nullptr, T, F, n_slabs, nullptr, nullptr, nullptr,
+                           out, ldo, nullptr, nullptr);
+    return check_launch("ggcn_aggregate_t");
+}
+
+// inv[i] = 1 / (sum of row i's values + 1)   (gcn.py:35), one thread per node
+__global__ __launch_bounds__(256) void inv_denominator_kernel(const int32_t *__restrict__ rowptr,
+                                                              const float *__restrict__ vals, int64_t n,
+                                                              float *__restrict__ inv)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 1.0f;
+    if (vals) {
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) s += vals[e];
+    } else {
+        s += (float)(rowptr[i + 1] - rowptr[i]);
+    }
+    inv[i] = 1.0f / s;
 }
 
 bool side_aligned(const float *bias, const float *sg, const float *ga, const float *gb)
@@ -275,6 +320,24 @@ int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t
                                 pool_gate_b, out, ldo, pool_a, pool_b, st);
     return launch<float, 1>(Hd, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
                             pool_gate_b, out, ldo, pool_a, pool_b, st);
+}
+
+int aggregate_t(const float *G, int64_t ldg, const int32_t *rowptr_t, const int32_t *colidx_t,
+                const float *vals_t, const float *src_scale, int B, int T, int F, float *out, int64_t ldo,
+                hipStream_t st)
+{
+    if (int rc = check_args(G, ldg, rowptr_t, colidx_t, B, T, F, out, ldo, nullptr, nullptr)) return rc;
+    if (!src_scale || !out) return fail(GGCN_EINVAL, "ggcn_aggregate_t: null pointer");
+    const bool vec = (F % 4 == 0) && (ldg % 4 == 0) && aligned16(G) && (ldo % 4 == 0) && aligned16(out);
+    return vec ? launch_t<4>(G, ldg, rowptr_t, colidx_t, vals_t, src_scale, B, T, F, out, ldo, st)
+               : launch_t<1>(G, ldg, rowptr_t, colidx_t, vals_t, src_scale, B, T, F, out, ldo, st);
+}
+
+int inv_denominators(const int32_t *rowptr, const float *vals, int64_t n, float *inv, hipStream_t st)
+{
+    if (!rowptr || !inv || n <= 0) return fail(GGCN_EINVAL, "ggcn_inv_denominators: bad argument");
+    hipLaunchKernelGGL(inv_denominator_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rowptr, vals, n, inv);
+    return check_launch("ggcn_inv_denominators");
 }
 
 int aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,

@@ -62,7 +62,25 @@ size_t ggcn_weight_pack_bytes(int K, int F) { return weight_pack_bytes(K, F); }
 
 int ggcn_weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, ggcn_stream_t stream)
 {
-    return weight_pack(W, ldw, K, F, wpack, as_stream(stream));
+    return weight_pack(W, ldw, K, F, wpack, false, as_stream(stream));
+}
+
+int ggcn_weight_pack_t(const float *W, int64_t ldw, int K, int F, void *wpack, ggcn_stream_t stream)
+{
+    return weight_pack(W, ldw, K, F, wpack, true, as_stream(stream));
+}
+
+int ggcn_aggregate_t(const float *G, int64_t ldg, const int32_t *rowptr_t, const int32_t *colidx_t,
+                     const float *vals_t, const float *src_scale, int B, int T, int F, float *out, int64_t ldo,
+                     ggcn_stream_t stream)
+{
+    return aggregate_t(G, ldg, rowptr_t, colidx_t, vals_t, src_scale, B, T, F, out, ldo, as_stream(stream));
+}
+
+int ggcn_inv_denominators(const int32_t *rowptr, const float *vals, int64_t n_rows, float *inv,
+                          ggcn_stream_t stream)
+{
+    return inv_denominators(rowptr, vals, n_rows, inv, as_stream(stream));
 }
 
 int ggcn_linear(const float *X, int64_t ldx, const float *W, int64_t ldw, const void *wpack, float *Y,

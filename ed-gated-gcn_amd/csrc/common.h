@@ -36,12 +36,16 @@ int linear_fp32(const float *X, int64_t ldx, const float *W, int64_t ldw, float 
                 int64_t M, int K, int F, hipStream_t st);
 
 size_t weight_pack_bytes(int K, int F);
-int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, hipStream_t st);
+int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, bool transposed, hipStream_t st);
 int linear_bf16x3(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy,
                   int64_t M, int K, int F, hipStream_t st);
 
 int linear_bf16x3_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M, int K,
                     int F, hipStream_t st);
+int aggregate_t(const float *G, int64_t ldg, const int32_t *rowptr_t, const int32_t *colidx_t,
+                const float *vals_t, const float *src_scale, int B, int T, int F, float *out, int64_t ldo,
+                hipStream_t st);
+int inv_denominators(const int32_t *rowptr, const float *vals, int64_t n, float *inv, hipStream_t st);
 int aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx, const float *vals,
                 const float *bias, int B, int T, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, void *out, int64_t ldo, float *pool_a, float *pool_b, hipStream_t st);

@@ -22,6 +22,9 @@ using namespace bx3;
 
 // ---- W -> fragment-ordered bf16 hi/lo image --------------------------------------------
 // block (n_tile, k_step), 128 threads: thread = (plane, lane)
+// TR: pack the TRANSPOSE of the stored matrix (element (k, n) is read from W[n*ldw + k]): the
+// backward pass multiplies by W^T (dX = dH . W^T) with the same kernels.
+template <bool TR>
 __global__ __launch_bounds__(128) void weight_pack_kernel(const float *__restrict__ W, int64_t ldw,
                                                           int K, int F, int k_steps,
                                                           bf16x8 *__restrict__ pack)
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(128) void weight_pack_kernel(const float *__restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = kb + j;
-        const float w = (k < K && n < F) ? W[(int64_t)k * ldw + n] : 0.0f;
+        const float w = (k < K && n < F) ? (TR ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n]) : 0.0f;
         const __bf16 hi = (__bf16)w;
         v[j] = plane == 0 ? hi : (__bf16)(w - (float)hi);
     }
@@ -140,16 +143,21 @@ size_t weight_pack_bytes(int K, int F)
     return n_tiles * k_steps * 2 * bx3::FRAG_BYTES;
 }
 
-int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, hipStream_t st)
+int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, bool transposed, hipStream_t st)
 {
     if (!W || !wpack) return fail(GGCN_EINVAL, "ggcn_weight_pack: null pointer");
-    if (K <= 0 || F <= 0 || ldw < F) return fail(GGCN_EINVAL, "ggcn_weight_pack: bad shape K=%d F=%d ldw=%lld", K, F, (long long)ldw);
+    if (K <= 0 || F <= 0 || ldw < (transposed ? K : F))
+        return fail(GGCN_EINVAL, "ggcn_weight_pack: bad shape K=%d F=%d ldw=%lld", K, F, (long long)ldw);
     if (!aligned16(wpack)) return fail(GGCN_EINVAL, "ggcn_weight_pack: wpack must be 16-byte aligned");
     const int k_steps = round_up(K, BK) / KSTEP;
     const int n_tiles = round_up(F, NT) / NT;
     if (k_steps > 65535) return fail(GGCN_EUNSUPPORTED, "ggcn_weight_pack: K too large");
-    hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)n_tiles, (unsigned)k_steps), dim3(128), 0, st, W,
-                       ldw, K, F, k_steps, static_cast<bf16x8 *>(wpack));
+    if (transposed)
+        hipLaunchKernelGGL(weight_pack_kernel<true>, dim3((unsigned)n_tiles, (unsigned)k_steps), dim3(128), 0, st, W,
+                           ldw, K, F, k_steps, static_cast<bf16x8 *>(wpack));
+    else
+        hipLaunchKernelGGL(weight_pack_kernel<false>, dim3((unsigned)n_tiles, (unsigned)k_steps), dim3(128), 0, st, W,
+                           ldw, K, F, k_steps, static_cast<bf16x8 *>(wpack));
     return check_launch("ggcn_weight_pack");
 }
 

@@ -41,7 +41,10 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2):
     csr = adj if isinstance(adj, BatchedCSR) else gc1._as_csr(adj, x)
     gcn1, x1, y1 = gc1.forward_gated(x, csr, store_gate=None, pool_gate_a=gate1, pool_gate_b=gate2,
                                      want_pool_a=True, want_pool_b=True)           # :626-636
-    xy = gate_overlap(x1, y1)                                                      # :638
+    if torch.is_grad_enabled() and (x1.requires_grad or y1.requires_grad):
+        xy = (x1 * y1).sum(1).mean()   # differentiable form of :638 (the regulariser is trained on)
+    else:
+        xy = gate_overlap(x1, y1)                                                  # :638
     x2, out, _ = gc2.forward_gated(gcn1, csr, store_gate=gate2, pool_gate_a=gate2,
                                    want_pool_a=True)                               # :639-640
     return {"gcn1": gcn1, "x1": x1, "y1": y1, "xy": xy, "x": x2, "out": out}

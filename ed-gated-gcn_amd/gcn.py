@@ -30,6 +30,62 @@ def _require_gpu_f32(name, t, allow_half=False):
         raise RuntimeError("%s must be float32%s, got %s" % (name, " or float16" if allow_half else "", t.dtype))
 
 
+class _GraphConvFunction(torch.autograd.Function):
+    """Y = D.A.(X.W) + b with the backward of ``train.py:115-121`` (autograd through gc1/gc2):
+
+        dH = A^T.(D.dY)   HIP, one wavefront per SOURCE node on the transposed CSR
+        dX = dH.W^T       HIP bf16x3 MFMA linear on the packed W^T
+        dW = X^T.dH       plain library GEMM (rocBLAS through torch.matmul)
+        db = sum_rows dY
+    """
+
+    @staticmethod
+    def forward(ctx, text, weight, bias, layer, csr):
+        with torch.no_grad():
+            out, _, _ = layer._forward_impl(text, csr)
+        ctx.layer, ctx.csr = layer, csr
+        ctx.save_for_backward(text, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        text, weight = ctx.saved_tensors
+        layer, csr = ctx.layer, ctx.csr
+        lib = _capi.load_library()
+        B, T, K = text.shape
+        F = layer.out_features
+        dev = text.device
+        dy2 = dy.reshape(B * T, F)
+        if dy2.dtype != torch.float32 or dy2.stride(1) != 1:
+            dy2 = dy2.float().contiguous()
+        csr_t = csr.transposed()
+        inv = csr.inv_denominators()
+        with torch.cuda.device(dev):
+            st = _capi.stream_of(dev)
+            dh = torch.empty(B * T, F, dtype=torch.float32, device=dev)
+            _capi.check(lib.ggcn_aggregate_t(_capi.ptr(dy2), dy2.stride(0), _capi.ptr(csr_t.rowptr),
+                                             _capi.ptr(csr_t.colidx), _capi.ptr(csr_t.vals), _capi.ptr(inv),
+                                             B, T, F, _capi.ptr(dh), F, st), "ggcn_aggregate_t")
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(B * T, K, dtype=torch.float32, device=dev)
+                if layer.precision == "bf16x3":
+                    pack_t = layer._packed_weight(lib, st, transposed=True)
+                    _capi.check(lib.ggcn_linear(_capi.ptr(dh), F, None, 0, _capi.ptr(pack_t), _capi.ptr(dx), K,
+                                                B * T, F, K, _capi.PREC["bf16x3"], st), "ggcn_linear(dX)")
+                else:
+                    wt = weight.detach().t().contiguous()
+                    _capi.check(lib.ggcn_linear(_capi.ptr(dh), F, _capi.ptr(wt), K, None, _capi.ptr(dx), K,
+                                                B * T, F, K, _capi.PREC["fp32"], st), "ggcn_linear(dX)")
+                dx = dx.view(B, T, K)
+            if ctx.needs_input_grad[1]:
+                dw = text.reshape(B * T, K).t().matmul(dh)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = dy2.sum(dim=0)
+        return dx, dw, db, None, None
+
+
 class GraphConvolution(nn.Module):
     """Mean-normalised GCN layer: ``(adj @ (text @ W)) / (rowsum(adj) + 1) + b``."""
 
@@ -54,19 +110,23 @@ class GraphConvolution(nn.Module):
             self.in_features, self.out_features, self.bias is not None, self.precision)
 
     # -- weight image for the bf16x3 linear, rebuilt only when the weight changes ----------
-    def _packed_weight(self, lib, stream):
+    def _packed_weight(self, lib, stream, transposed=False):
+        """bf16 hi/lo image of W (forward) or W^T (backward's dX), rebuilt when W changes."""
         w = self.weight
         key = (w.data_ptr(), w._version, w.device)
-        if self._pack is None or self._pack_key != key:
-            nbytes = lib.ggcn_weight_pack_bytes(self.in_features, self.out_features)
-            pack = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        slot = 1 if transposed else 0
+        if self._pack is None:
+            self._pack, self._pack_key = [None, None], [None, None]
+        if self._pack[slot] is None or self._pack_key[slot] != key:
+            K, F = (self.out_features, self.in_features) if transposed else (self.in_features, self.out_features)
+            pack = torch.empty(lib.ggcn_weight_pack_bytes(K, F), dtype=torch.uint8, device=w.device)
             wc = w.detach()
             if not wc.is_contiguous():
                 wc = wc.contiguous()
-            _capi.check(lib.ggcn_weight_pack(_capi.ptr(wc), self.out_features, self.in_features,
-                                             self.out_features, _capi.ptr(pack), stream), "ggcn_weight_pack")
-            self._pack, self._pack_key = pack, key
-        return self._pack
+            fn = lib.ggcn_weight_pack_t if transposed else lib.ggcn_weight_pack
+            _capi.check(fn(_capi.ptr(wc), self.out_features, K, F, _capi.ptr(pack), stream), "ggcn_weight_pack")
+            self._pack[slot], self._pack_key[slot] = pack, key
+        return self._pack[slot]
 
     def _as_csr(self, adj, text):
         if isinstance(adj, BatchedCSR):
@@ -94,11 +154,6 @@ class GraphConvolution(nn.Module):
             raise RuntimeError("text must be [B,T,%d], got %s" % (self.in_features, tuple(text.shape)))
         if self.weight.device != text.device:
             raise RuntimeError("weight is on %s but text is on %s" % (self.weight.device, text.device))
-        if torch.is_grad_enabled() and (text.requires_grad or self.weight.requires_grad
-                                        or (self.bias is not None and self.bias.requires_grad)):
-            raise NotImplementedError(
-                "the HIP gated-GCN path is forward/inference only in this build: call it under "
-                "torch.no_grad() (as train.py:223 does for evaluation)")
         if self.precision not in _capi.PREC:
             raise RuntimeError("unknown precision %r (use 'bf16x3' or 'fp32')" % (self.precision,))
 
@@ -110,7 +165,7 @@ class GraphConvolution(nn.Module):
             st = _capi.stream_of(dev)
             y = torch.empty(x2d.shape[0], self.out_features, dtype=x2d.dtype, device=dev)
             if x2d.dtype == torch.float16:
-                pack = self._packed_weight(lib, st)
+                pack = self._packed_weight(lib, st)  # noqa
                 _capi.check(lib.ggcn_linear_h(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack), _capi.ptr(y),
                                               y.stride(0), x2d.shape[0], self.in_features, self.out_features, st),
                             "ggcn_linear_h")
@@ -125,8 +180,15 @@ class GraphConvolution(nn.Module):
                         "ggcn_linear")
         return y
 
+    def _needs_grad(self, text):
+        return torch.is_grad_enabled() and (text.requires_grad or self.weight.requires_grad
+                                            or (self.bias is not None and self.bias.requires_grad))
+
+    def _forward_impl(self, text, csr):
+        return self.forward_gated(text, csr, _internal=True)
+
     def forward_gated(self, text, adj, store_gate=None, pool_gate_a=None, pool_gate_b=None,
-                      want_out=True, want_pool_a=False, want_pool_b=False):
+                      want_out=True, want_pool_a=False, want_pool_b=False, _internal=False):
         """Layer + gate + max-pool in one aggregation pass.
 
         Returns ``(out [B,T,F] or None, pool_a [B,F] or None, pool_b [B,F] or None)`` with
@@ -134,6 +196,20 @@ class GraphConvolution(nn.Module):
         plain layer output.  Gates are ``[B,F]`` (broadcast over tokens)."""
         self._check(text)
         csr = self._as_csr(adj, text)
+        if not _internal and self._needs_grad(text):
+            # training: autograd through the layer itself; gate and max-pool as differentiable
+            # torch ops on its output, exactly as the reference writes them (bert_amir5.py:627-640)
+            if text.dtype != torch.float32:
+                raise RuntimeError("training through the HIP layer needs float32 features")
+            y = _GraphConvFunction.apply(text, self.weight, self.bias, self, csr)
+            out = pa = pb = None
+            if want_out:
+                out = y if store_gate is None else y * store_gate[:, None, :]
+            if want_pool_a:
+                pa = (y if pool_gate_a is None else y * pool_gate_a[:, None, :]).max(dim=1)[0]
+            if want_pool_b:
+                pb = (y if pool_gate_b is None else y * pool_gate_b[:, None, :]).max(dim=1)[0]
+            return out, pa, pb
         lib = _capi.load_library()
         B, T, _ = text.shape
         F = self.out_features

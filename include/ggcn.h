@@ -124,6 +124,23 @@ int ggcn_aggregate(const float *Hd, int64_t ldh,
                    float *out, int64_t ldo, float *pool_a, float *pool_b,
                    ggcn_stream_t stream);
 
+/* ---- backward pass of the layer (train.py:115-121 trains through gc1/gc2) ----------------
+ * For Y = D.A.(X.W) + b with D = diag(1/(rowsum(A)+1)) and an upstream gradient dY [N,F]:
+ *   dH = A^T.(D.dY)   ggcn_aggregate_t on the TRANSPOSED adjacency (CSR of adj^T: rows = source
+ *                     nodes), src_scale = the 1/(rowsum+1) of the ORIGINAL rows from
+ *                     ggcn_inv_denominators;  out[j] = sum_e vals_t[e]*src_scale[colidx_t[e]]*G[colidx_t[e]]
+ *   dX = dH.W^T       ggcn_linear with the image made by ggcn_weight_pack_t
+ *                     (packs the transpose of the stored [K_stored x ldw] matrix: the packed
+ *                     operand has K = F_layer rows and F = K_layer columns)
+ *   dW = X^T.dH, db = sum_rows dY   plain library GEMM / reduction on the caller's side. */
+int ggcn_weight_pack_t(const float *W, int64_t ldw, int K, int F, void *wpack, ggcn_stream_t stream);
+int ggcn_inv_denominators(const int32_t *rowptr, const float *vals, int64_t n_rows, float *inv,
+                          ggcn_stream_t stream);
+int ggcn_aggregate_t(const float *G, int64_t ldg,
+                     const int32_t *rowptr_t, const int32_t *colidx_t, const float *vals_t,
+                     const float *src_scale, int B, int T, int F,
+                     float *out, int64_t ldo, ggcn_stream_t stream);
+
 /* ---- fp16 features (BASELINE configs[3]: 512-token graphs, hidden 1024) ------------------
  * Same operations with X / hidden / out stored as IEEE half and fp32 accumulation; weights
  * (wpack), bias, gates and pooled outputs stay fp32.  The reference cannot run half inputs

@@ -246,8 +246,6 @@ def test_errors_are_loud(pkg, dev):
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             m(x.cpu(), torch.zeros(2, 4, 4))                   # no CPU path
-    with pytest.raises(NotImplementedError):
-        m(x, torch.zeros(2, 4, 4, device=dev))                 # grad-enabled: forward-only build
 
 
 # ---------------------------------------------------------------- full-size properties (config 2)
@@ -367,3 +365,87 @@ def test_fp16_features_config4(pkg, dev, B, T, H):
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             mf(x16.to(dev), torch.from_numpy(adj).to(dev))
+
+
+# ---------------------------------------------------------------- backward
+def _grad_close(got, want, name, rel=2e-4):
+    scale = float(want.abs().max()) + 1e-12
+    err = float((got.cpu() - want).abs().max())
+    assert err <= rel * scale, "%s: max|diff| %.3g vs scale %.3g" % (name, err, scale)
+
+
+@pytest.mark.parametrize("precision,fused", MODES, ids=MODE_IDS)
+@pytest.mark.parametrize("B,T,K,F,weighted", [(8, 32, 256, 256, False), (3, 100, 64, 48, True), (5, 17, 34, 20, False)])
+def test_layer_backward_vs_oracle_autograd(pkg, dev, precision, fused, B, T, K, F, weighted):
+    """train.py:115-121 trains through gc1/gc2: gradients of the HIP layer (transposed-CSR
+    aggregation + MFMA dX + library dW) against torch autograd on the oracle's dense forward."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(B + T + K)
+    adj = synth.dependency_batch(B, T, min(4.0, T), seed=5, lengths=rng.integers(2, T + 1, size=B)).astype(np.float32)
+    if weighted:
+        adj = adj * rng.uniform(0.5, 1.5, adj.shape).astype(np.float32)   # asymmetric weights
+    x = torch.from_numpy(rng.standard_normal((B, T, K)).astype(np.float32))
+    w, b = synth.layer_params(K, F, seed=6)
+    R = torch.from_numpy(rng.standard_normal((B, T, F)).astype(np.float32))
+    xr, wr, br = x.clone().requires_grad_(), torch.from_numpy(w).requires_grad_(), torch.from_numpy(b).requires_grad_()
+    (ref_dense.graph_convolution(xr, torch.from_numpy(adj), wr, br) * R).sum().backward()
+    m = _layer(pkg, dev, w, b, precision, fused).train()
+    xg = x.to(dev).requires_grad_()
+    out = m(xg, torch.from_numpy(adj).to(dev))
+    (out * R.to(dev)).sum().backward()
+    _grad_close(xg.grad, xr.grad, "d text")
+    _grad_close(m.weight.grad, wr.grad, "d weight")
+    _grad_close(m.bias.grad, br.grad, "d bias")
+
+
+@pytest.mark.parametrize("precision,fused", MODES, ids=MODE_IDS)
+def test_gated_block_backward_vs_oracle_autograd(pkg, dev, precision, fused):
+    """The whole block of bert_amir5.py:621-640 under autograd: loss touches out, x and xy
+    (train.py:115-117: CE + gate_w*xy + ...)."""
+    from ed_gated_gcn_amd import synth
+    B, T, H = 12, 31, 128
+    rng = np.random.default_rng(77)
+    adj = synth.dependency_batch(B, T, 3.5, seed=8, lengths=rng.integers(4, T + 1, size=B))
+    t = torch.from_numpy
+    x = t(rng.standard_normal((B, T, H)).astype(np.float32))
+    g1 = torch.sigmoid(t(rng.standard_normal((B, H)).astype(np.float32)))
+    g2 = torch.sigmoid(t(rng.standard_normal((B, H)).astype(np.float32)))
+    w1, b1 = synth.layer_params(H, H, seed=1)
+    w2, b2 = synth.layer_params(H, H, seed=2)
+    R1 = t(rng.standard_normal((B, H)).astype(np.float32))
+    R2 = t(rng.standard_normal((B, T, H)).astype(np.float32))
+
+    def loss_of(r, R1, R2):
+        return (r["out"] * R1).sum() + 0.1 * (r["x"] * R2).sum() + 0.01 * r["xy"]
+
+    gc1, gc2 = _layer(pkg, dev, w1, b1, precision, fused).train(), _layer(pkg, dev, w2, b2, precision, fused).train()
+    xg, g1g, g2g = (v.to(dev).requires_grad_() for v in (x, g1, g2))
+    r = pkg.gated_gcn_block(xg, t(adj).to(dev), g1g, g2g, gc1, gc2)
+    loss_of(r, R1.to(dev), R2.to(dev)).backward()
+
+    # Reference gradients: torch autograd on the oracle's formula.  A max-pool routes its gradient
+    # to the argmax row, and a ~1e-5 forward difference (bf16x3) can flip a near-tie, so the
+    # reference takes the rows the GPU forward selected (gather instead of max); that the
+    # selections are maxima of the reference values too is asserted separately.
+    with torch.no_grad():
+        i_x1 = (r["gcn1"] * g1g[:, None, :]).argmax(dim=1).cpu()
+        i_y1 = (r["gcn1"] * g2g[:, None, :]).argmax(dim=1).cpu()
+        i_out = r["x"].argmax(dim=1).cpu()
+    leaves = [v.clone().requires_grad_() for v in (x, g1, g2, t(w1), t(b1), t(w2), t(b2))]
+    lx, lg1, lg2, lw1, lb1, lw2, lb2 = leaves
+    a32 = t(adj.astype(np.float32))
+    gcn1 = ref_dense.graph_convolution(lx, a32, lw1, lb1)
+    x2 = lg2[:, None, :] * ref_dense.graph_convolution(gcn1, a32, lw2, lb2)
+    pick = lambda v, i: v.gather(1, i[:, None, :]).squeeze(1)
+    rr = {"x": x2, "out": pick(x2, i_out),
+          "xy": (pick(gcn1 * lg1[:, None, :], i_x1) * pick(gcn1 * lg2[:, None, :], i_y1)).sum(1).mean()}
+    assert float((x2.max(dim=1)[0] - rr["out"]).detach().abs().max()) <= 1e-4      # the picks are (near-)maxima
+    loss_of(rr, R1, R2).backward()
+    got = [xg.grad, g1g.grad, g2g.grad, gc1.weight.grad, gc1.bias.grad, gc2.weight.grad, gc2.bias.grad]
+    for name, gv, lv in zip(("x", "gate1", "gate2", "w1", "b1", "w2", "b2"), got, leaves):
+        _grad_close(gv, lv.grad, name, rel=5e-4)
+    # forward values under autograd equal the inference path
+    with torch.no_grad():
+        ri = pkg.gated_gcn_block(xg.detach(), t(adj).to(dev), g1g.detach(), g2g.detach(), gc1, gc2)
+    for k in ("gcn1", "x", "out", "x1", "y1"):
+        assert torch.max(torch.abs(ri[k] - r[k].detach())).item() <= 4e-5, k
