@@ -19,5 +19,7 @@ from ._capi import lib_path, load_library  # noqa: F401
 from .csr import BatchedCSR  # noqa: F401
 from .gcn import GraphConvolution  # noqa: F401
 from .gated_block import gated_gcn_block  # noqa: F401
+from .classifier import GatedGCNEventDetector, LegacyBertAdapter  # noqa: F401
 
-__all__ = ["GraphConvolution", "gated_gcn_block", "BatchedCSR", "load_library", "lib_path"]
+__all__ = ["GraphConvolution", "gated_gcn_block", "BatchedCSR", "GatedGCNEventDetector", "LegacyBertAdapter",
+           "load_library", "lib_path"]

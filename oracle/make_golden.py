@@ -144,19 +144,8 @@ def make_g2(GraphConvolution, out_dir):
     np.savez_compressed(os.path.join(out_dir, "gcn_sweep.npz"), **blob)
 
 
-class _EncoderStandIn(torch.nn.Module):
-    """Returns seeded hidden states in the pytorch_pretrained_bert form used at
-    models/bert_amir5.py:591-596: (list of 12 tensors [B,L,768], pooled [B,768])."""
-
-    def __init__(self, seed):
-        super().__init__()
-        self.seed = seed
-
-    def forward(self, ids, seg, output_all_encoded_layers=True):
-        g = torch.Generator().manual_seed(self.seed)
-        B, L = ids.shape
-        layers = [torch.randn(B, L, 768, generator=g) * 0.5 for _ in range(12)]
-        return layers, torch.randn(B, 768, generator=g)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle.ref_amir55 import EncoderStandIn as _EncoderStandIn  # noqa: E402  (seeded encoder stand-in)
 
 
 def make_g3(BertAmir55, out_dir):
@@ -229,6 +218,14 @@ def make_g3(BertAmir55, out_dir):
               "fc.0.weight", "fc.0.bias"):
         blob["p_" + k] = sd[k].numpy()
     np.savez_compressed(os.path.join(out_dir, "amir55_block.npz"), **blob)
+    # G4: the whole classifier.  Inputs + the reference's outputs + the seeds: the parameters are
+    # re-drawn from the seed on the test side (40 MB of LSTM weights do not belong in a fixture).
+    full = {"seed_params": np.array(SEED + 2), "seed_encoder": np.array(SEED + 3),
+            "n_class": np.array(NCLS), "logits": logits.numpy(), "xy": xy.numpy(), "kl": kl.numpy(),
+            "scores": scores.numpy()}
+    for k, v in inputs.items():
+        full["in_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(out_dir, "amir55_full.npz"), **full)
 
 
 def main():

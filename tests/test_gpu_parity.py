@@ -449,3 +449,78 @@ def test_gated_block_backward_vs_oracle_autograd(pkg, dev, precision, fused):
         ri = pkg.gated_gcn_block(xg.detach(), t(adj).to(dev), g1g.detach(), g2g.detach(), gc1, gc2)
     for k in ("gcn1", "x", "out", "x1", "y1"):
         assert torch.max(torch.abs(ri[k] - r[k].detach())).item() <= 4e-5, k
+
+
+# ---------------------------------------------------------------- config 5: the classifier end to end
+def _ace_batch(rng, B, ORI_ML, BERT_ML, vocab=None):
+    from ed_gated_gcn_amd import synth
+    sent_len = rng.integers(5, ORI_ML + 1, size=B)
+    sent_len[0] = ORI_ML
+    bert_len = np.minimum(sent_len + rng.integers(2, 10, size=B), BERT_ML)
+    adj = synth.dependency_batch(B, ORI_ML, 3.5, seed=12, lengths=sent_len).astype(np.float32)
+    transform = np.zeros((B, ORI_ML, BERT_ML), dtype=np.float32)
+    for b in range(B):                                   # word <- word pieces (data_utils.py:749-766 shape)
+        for tkn in range(int(sent_len[b])):
+            transform[b, tkn, 1 + min(tkn, BERT_ML - 2)] = 1.0
+    ids = np.zeros((B, BERT_ML), dtype=np.int64) if vocab is None else rng.integers(0, vocab, size=(B, BERT_ML))
+    return {
+        "sentence_length": torch.from_numpy(sent_len), "cls_text_sep_length": torch.from_numpy(bert_len),
+        "cls_text_sep_indices": torch.from_numpy(ids),
+        "cls_text_sep_segments_ids": torch.zeros(B, BERT_ML, dtype=torch.long),
+        "transform": torch.from_numpy(transform),
+        "anchor_index": torch.from_numpy(np.array([int(rng.integers(0, n)) for n in sent_len])),
+        "dist_to_target": torch.from_numpy(rng.integers(0, 6, size=(B, ORI_ML))),
+        "dependency_graph": torch.from_numpy(adj),
+    }
+
+
+def test_config5_classifier_golden_reference_logits(pkg, dev, golden_dir):
+    """G4: the HIP-backed classifier with the reference's seeded parameters and encoder stand-in
+    against the logits the REFERENCE BertAmir55 produced (BASELINE configs[4], 1e-3)."""
+    import types
+    from oracle.ref_amir55 import BertAmir55Oracle, EncoderStandIn
+    g = np.load(os.path.join(golden_dir, "amir55_full.npz"))
+    oracle = BertAmir55Oracle(EncoderStandIn(int(g["seed_encoder"])), int(g["n_class"]))
+    oracle.seeded_init(torch.Generator().manual_seed(int(g["seed_params"])))
+    opt = types.SimpleNamespace(device=dev, dropout=0.25, polarities_dim=int(g["n_class"]))
+    model = pkg.GatedGCNEventDetector(EncoderStandIn(int(g["seed_encoder"])), opt)
+    model.load_state_dict(oracle.state_dict())           # same keys as the reference's state_dict
+    model = model.to(dev).eval()
+    inputs = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    with torch.no_grad():
+        logits, xy, kl, scores = model(inputs)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(scores.cpu().numpy(), g["scores"], rtol=0, atol=1e-2)
+    assert abs(float(xy) - float(g["xy"])) <= 1e-3 * abs(float(g["xy"]))
+    assert abs(float(kl) - float(g["kl"])) <= 1e-4
+
+
+def test_config5_bert_base_end_to_end(pkg, dev):
+    """BASELINE configs[4]: randomly-initialised BERT-base (transformers.BertConfig(), no fetch)
+    on PyTorch-ROCm + HIP gated GCN on a synthetic ACE-2005-shaped batch; logits within 1e-3 of
+    the CPU oracle classifier run with the same state_dict."""
+    import types
+    transformers = pytest.importorskip("transformers")
+    from oracle.ref_amir55 import BertAmir55Oracle
+    torch.manual_seed(5)
+    cfg = transformers.BertConfig()                       # bert-base shape: 12 layers, 768 hidden
+    hf = transformers.BertModel(cfg).eval()
+    B, ORI_ML, BERT_ML, NCLS = 8, 31, 65, 34              # constant.py:230-238 (ACE34)
+    rng = np.random.default_rng(3)
+    inputs = _ace_batch(rng, B, ORI_ML, BERT_ML, vocab=cfg.vocab_size)
+    oracle = BertAmir55Oracle(pkg.LegacyBertAdapter(hf), NCLS)
+    oracle.seeded_init(torch.Generator().manual_seed(9))
+    oracle.eval()
+    with torch.no_grad():
+        ref_logits, ref_xy, ref_kl, ref_scores = oracle(inputs)
+    opt = types.SimpleNamespace(device=dev, dropout=0.25, polarities_dim=NCLS)
+    import copy
+    model = pkg.GatedGCNEventDetector(pkg.LegacyBertAdapter(copy.deepcopy(hf)), opt)
+    model.load_state_dict(oracle.state_dict())
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        logits, xy, kl, scores = model({k: v.to(dev) for k, v in inputs.items()})
+    assert logits.shape == (B, NCLS) and scores.shape == (B, ORI_ML)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.numpy(), rtol=0, atol=1e-3)
+    assert abs(float(xy) - float(ref_xy)) <= 1e-3 * abs(float(ref_xy))
+    assert abs(float(kl) - float(ref_kl)) <= 1e-4

@@ -92,3 +92,21 @@ def test_gate_mlp_matches_fixture(golden_dir):
         h = torch.sigmoid(h @ torch.from_numpy(g["p_%s.1.weight" % name]).T + torch.from_numpy(g["p_%s.1.bias" % name]))
         h = torch.sigmoid(h @ torch.from_numpy(g["p_%s.3.weight" % name]).T + torch.from_numpy(g["p_%s.3.bias" % name]))
         np.testing.assert_allclose(h.numpy(), g[name], rtol=0, atol=1e-6)
+
+
+def test_full_classifier_restatement_reproduces_bertamir55(golden_dir):
+    """G4: BertAmir55Oracle with the seeded train.py:75-84 parameters and the seeded encoder
+    stand-in must give the logits / xy / kl / scores the REFERENCE class produced."""
+    from oracle.ref_amir55 import BertAmir55Oracle, EncoderStandIn
+    g = _load(golden_dir, "amir55_full.npz")
+    torch.set_num_threads(1)
+    model = BertAmir55Oracle(EncoderStandIn(int(g["seed_encoder"])), int(g["n_class"]))
+    model.seeded_init(torch.Generator().manual_seed(int(g["seed_params"])))
+    model.eval()
+    inputs = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    with torch.no_grad():
+        logits, xy, kl, scores = model(inputs)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(scores.numpy(), g["scores"], rtol=0, atol=2e-5)
+    assert abs(float(xy) - float(g["xy"])) <= 1e-6 * abs(float(g["xy"]))
+    assert abs(float(kl) - float(g["kl"])) <= 1e-6
