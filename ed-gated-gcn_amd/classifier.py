@@ -57,7 +57,9 @@ class GatedGCNEventDetector(nn.Module):
         transform = inputs["transform"][:, :T, :L]
         anchor = inputs["anchor_index"]
         dist = inputs["dist_to_target"][:, :T]
-        adj = inputs["dependency_graph"][:, :T, :T]                         # dense slice or a BatchedCSR
+        adj = inputs["dependency_graph"]                                    # :589 dense slice, or a BatchedCSR
+        if isinstance(adj, torch.Tensor):
+            adj = adj[:, :T, :T]
         x, pooled = self.bert(ids, seg, output_all_encoded_layers=True)     # :591
         x = torch.cat(x[-self.n_layer:], dim=-1)                            # :596
         x = torch.bmm(transform, x)                                         # :600

@@ -36,6 +36,7 @@ namespace bx3 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 256, BK = 32;
@@ -141,6 +142,36 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         const int row = stage_row<AT>(i);
         const int off = a_lds_off(row, s_k >> 3) + (s_k & 4) * 2;
         const int gk = k0 + s_k;
+#if defined(GGCN_SPLIT_PAIRWISE)
+        // pairwise: hi pair = one v_cvt_pk_bf16_f32; float(hi) = the two halves of that dword
+        // (shift / mask); lo pair = one more v_cvt_pk of the two residuals  -> 6 VALU per pair.
+        // Fewer instructions than the per-element form below, but measured SLOWER (fused 492 vs
+        // 462 us, same process): kept for reference only.
+        uint32_t hw[EPT / 2], lw[EPT / 2];
+#pragma unroll
+        for (int c = 0; c < EPT; c += 2) {
+            float x0 = ra[i][c], x1 = ra[i][c + 1];
+            if constexpr (!KFULL || ZROWS) {
+                bool in0 = true, in1 = true;
+                if constexpr (!KFULL) { in0 = gk + c < K; in1 = gk + c + 1 < K; }
+                if constexpr (ZROWS) { in0 = in0 && avalid[i]; in1 = in1 && avalid[i]; }
+                x0 = in0 ? x0 : 0.0f;
+                x1 = in1 ? x1 : 0.0f;
+            }
+            const bf16x2 h = {(__bf16)x0, (__bf16)x1};
+            const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+            const bf16x2 l = {(__bf16)(x0 - __uint_as_float(hb << 16)), (__bf16)(x1 - __uint_as_float(hb & 0xffff0000u))};
+            hw[c / 2] = hb;
+            lw[c / 2] = __builtin_bit_cast(uint32_t, l);
+        }
+        if constexpr (EPT == 4) {
+            *reinterpret_cast<uint2 *>(hi_plane + off) = make_uint2(hw[0], hw[1]);
+            *reinterpret_cast<uint2 *>(lo_plane + off) = make_uint2(lw[0], lw[1]);
+        } else {
+            *reinterpret_cast<uint4 *>(hi_plane + off) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            *reinterpret_cast<uint4 *>(lo_plane + off) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        }
+#else
         __bf16 hi[EPT], lo[EPT];
 #pragma unroll
         for (int c = 0; c < EPT; ++c) {
@@ -161,6 +192,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             *reinterpret_cast<bf16x8 *>(hi_plane + off) = bf16x8{hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
             *reinterpret_cast<bf16x8 *>(lo_plane + off) = bf16x8{lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
         }
+#endif
     };
 
     // B fragments straight from the packed image; indices clamped, never predicated: a column

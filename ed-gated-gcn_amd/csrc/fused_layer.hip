@@ -42,7 +42,7 @@ __device__ __forceinline__ void split2(const f32x16 &acc, bf16x8 (&frag)[2][2])
         }
 }
 
-// FULLT: T == 32 (no padded rows inside a graph slot): drops every per-row guard.
+// FULLT: T == 32 and B % 4 == 0 (every row of every tile is a real node): drops every guard.
 template <bool AVEC, bool KFULL, bool FULLT>
 __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
     const float *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
     }
 
     f32x16 acc[4][2];
-    mainloop<float, AVEC, KFULL, true>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);
+    mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);
 
     const int c = lane & 31, h = lane >> 5;
 
@@ -225,7 +225,7 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
     const int64_t grid = grid_for(g_tiles, n_wg);
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: batch too large");
     const char *wp = static_cast<const char *>(wpack);
-    const bool fullt = (T == 32);
+    const bool fullt = (T == 32) && (B % 4 == 0);
 #define GGCN_LAUNCH(AV, KF, FT)                                                                                  \
     hipLaunchKernelGGL((layer_fused_kernel<AV, KF, FT>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
                        rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, (int)ldo, pool_a,    \
