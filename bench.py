@@ -196,7 +196,7 @@ def main():
     lin_flops = 2.0 * N * H * H                       # algorithmic flops of gcn.py:34 per launch
     agg_flops = 2.0 * nnz * H                         # gcn.py:41 on the non-zeros
     lin_peak = MFMA_BF16_PEAK_TF if args.precision == "bf16x3" else MFMA_F32_PEAK_TF
-    fused_path = gc1.fused and args.precision == "bf16x3" and csr.rowmask is not None and csr.vals is None
+    fused_path = gc1.fused and args.precision == "bf16x3" and csr.rowmask is not None and csr.is_binary
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch, if recorded
     measured = json.load(open(tpath)) if os.path.exists(tpath) else {}

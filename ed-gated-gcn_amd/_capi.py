@@ -20,6 +20,7 @@ PROTOTYPES = {
     "ggcn_csr_workspace_bytes": (c_sz, [c_i64]),
     "ggcn_csr_from_dense": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp,
                                     c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "ggcn_rowmask_from_dense": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "ggcn_csr_rowmask": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_layer_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                  c_vp, c_i64, c_vp, c_vp, c_vp]),

@@ -18,36 +18,76 @@ _ADJ_DTYPES = {
 
 class BatchedCSR:
     """rowptr int32[N+1], colidx int32[cap], vals fp32[cap] or None (binary adjacency),
-    rowmask uint32-as-int32[N] or None (T <= 32: bit j of word i = edge i<-j), on one GPU."""
+    rowmask uint32-as-int32[N] or None (T <= 32: bit j of word i = edge i<-j), on one GPU.
 
-    __slots__ = ("rowptr", "colidx", "vals", "rowmask", "B", "T", "nnz", "_dense", "_host", "_t", "_inv")
+    Built from a dense adjacency with T <= 32 only the row masks are computed up front (one
+    kernel: all the fused layer needs); the CSR arrays are materialised on first access."""
+
+    __slots__ = ("_rowptr", "_colidx", "_vals", "rowmask", "B", "T", "nnz", "is_binary",
+                 "_dense", "_host", "_t", "_inv")
 
     def __init__(self, rowptr, colidx, vals, B, T, nnz=None, rowmask=None):
-        self.rowptr, self.colidx, self.vals, self.rowmask = rowptr, colidx, vals, rowmask
+        self._rowptr, self._colidx, self._vals, self.rowmask = rowptr, colidx, vals, rowmask
         self.B, self.T, self.nnz = int(B), int(T), nnz
-        self._dense = None   # the dense tensor this CSR was built from (kept for transposed())
+        self.is_binary = vals is None
+        self._dense = None   # the dense tensor this CSR was built from (lazy arrays, transposed())
         self._host = None    # (rowptr, colidx, vals) numpy arrays when built on the host
         self._t = None       # cached CSR of the transposed adjacency (backward pass)
         self._inv = None     # cached 1/(rowsum+1) per node
 
     @property
     def device(self):
-        return self.rowptr.device
+        return self.rowmask.device if self._rowptr is None else self._rowptr.device
 
     @property
     def n_nodes(self):
         return self.B * self.T
 
+    @property
+    def rowptr(self):
+        self._materialize()
+        return self._rowptr
+
+    @property
+    def colidx(self):
+        self._materialize()
+        return self._colidx
+
+    @property
+    def vals(self):
+        self._materialize()
+        return self._vals
+
+    def _materialize(self):
+        if self._rowptr is not None:
+            return
+        adj = self._dense
+        lib = _capi.load_library()
+        B, T = self.B, self.T
+        dev = adj.device
+        n, cap = B * T, B * T * T
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        colidx = torch.empty(cap, dtype=torch.int32, device=dev)
+        vals = None if self.is_binary else torch.empty(cap, dtype=torch.float32, device=dev)
+        ws = torch.empty(max(1, lib.ggcn_csr_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        sb, sr, sc = adj.stride()
+        with torch.cuda.device(dev):
+            rc = lib.ggcn_csr_from_dense(_capi.ptr(adj), _ADJ_DTYPES[adj.dtype], B, T, sb, sr, sc,
+                                         _capi.ptr(rowptr), _capi.ptr(colidx), _capi.ptr(vals), cap,
+                                         None, None, _capi.ptr(ws), _capi.stream_of(dev))
+        _capi.check(rc, "ggcn_csr_from_dense")
+        self._rowptr, self._colidx, self._vals = rowptr, colidx, vals
+
     @classmethod
     def from_dense(cls, adj, binary=None):
         """Device-side conversion of a dense [B,T,T] adjacency (any real dtype, any strides).
 
-        colidx/vals are sized for the worst case B*T*T and ``nnz`` stays unknown (None).
-        ``binary=True`` promises a 0/1 adjacency (no value array, no host sync; the kernels
-        use deg+1 as the denominator, ``models/gcn.py:35``); ``binary=False`` keeps the
-        values as edge weights; ``binary=None`` (default) lets the device decide: the
-        builder raises a flag when some non-zero differs from 1 and this call reads that one
-        int back (one stream sync -- the reference's forward syncs too, ``bert_amir5.py:580``)."""
+        ``binary=True`` promises a 0/1 adjacency (no value array, no host sync; the kernels use
+        deg+1 as the denominator, ``models/gcn.py:35``); ``binary=False`` keeps the values as edge
+        weights; ``binary=None`` (default) lets the device decide: the builder raises a flag when
+        some non-zero differs from 1 and this call reads that one int back (one stream sync -- the
+        reference's forward syncs too, ``bert_amir5.py:580``).  colidx/vals are sized for the worst
+        case B*T*T; ``nnz`` stays unknown (None)."""
         if not isinstance(adj, torch.Tensor) or adj.dim() != 3 or adj.shape[1] != adj.shape[2]:
             raise RuntimeError("adj must be a [B,T,T] tensor, got %r" % (getattr(adj, "shape", None),))
         if not adj.is_cuda:
@@ -58,24 +98,32 @@ class BatchedCSR:
         B, T, _ = adj.shape
         dev = adj.device
         n = B * T
+        flags = torch.empty(1, dtype=torch.int32, device=dev) if binary is None else None
+        sb, sr, sc = adj.stride()
+        out = cls(None, None, None, B, T)
+        out._dense = adj
+        if T <= 32:
+            out.rowmask = torch.empty(n, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.ggcn_rowmask_from_dense(_capi.ptr(adj), _ADJ_DTYPES[adj.dtype], B, T, sb, sr, sc,
+                                                 _capi.ptr(out.rowmask), _capi.ptr(flags), _capi.stream_of(dev))
+            _capi.check(rc, "ggcn_rowmask_from_dense")
+            out.is_binary = bool(binary) if binary is not None else not (int(flags.item()) & _capi.FLAG_WEIGHTED)
+            return out
         cap = n * T
         rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         colidx = torch.empty(cap, dtype=torch.int32, device=dev)
         vals = None if binary is True else torch.empty(cap, dtype=torch.float32, device=dev)
-        rowmask = torch.empty(n, dtype=torch.int32, device=dev) if T <= 32 else None
-        flags = torch.empty(1, dtype=torch.int32, device=dev) if binary is None else None
         ws = torch.empty(max(1, lib.ggcn_csr_workspace_bytes(n)), dtype=torch.uint8, device=dev)
-        sb, sr, sc = adj.stride()
         with torch.cuda.device(dev):
             rc = lib.ggcn_csr_from_dense(_capi.ptr(adj), _ADJ_DTYPES[adj.dtype], B, T, sb, sr, sc,
                                          _capi.ptr(rowptr), _capi.ptr(colidx), _capi.ptr(vals), cap,
-                                         _capi.ptr(rowmask), _capi.ptr(flags), _capi.ptr(ws),
-                                         _capi.stream_of(dev))
+                                         None, _capi.ptr(flags), _capi.ptr(ws), _capi.stream_of(dev))
         _capi.check(rc, "ggcn_csr_from_dense")
         if binary is None and not (int(flags.item()) & _capi.FLAG_WEIGHTED):
             vals = None
-        out = cls(rowptr, colidx, vals, B, T, rowmask=rowmask)
-        out._dense = (adj, vals is None)
+        out._rowptr, out._colidx, out._vals = rowptr, colidx, vals
+        out.is_binary = vals is None
         return out
 
     @classmethod
@@ -111,8 +159,7 @@ class BatchedCSR:
         A^T.  Built from the dense tensor by swapping its strides, or on the host from the arrays."""
         if self._t is None:
             if self._dense is not None:
-                adj, binary = self._dense
-                self._t = BatchedCSR.from_dense(adj.transpose(1, 2), binary=binary)
+                self._t = BatchedCSR.from_dense(self._dense.transpose(1, 2), binary=self.is_binary)
             elif self._host is not None:
                 import numpy as np
                 import scipy.sparse as sp

@@ -68,17 +68,37 @@ __device__ __forceinline__ int a_lds_off(int row, int chunk) { return row * ROWB
 template <typename AT>
 __device__ __forceinline__ int stage_row(int p) { return p * Geom<AT>::RPP + (int)threadIdx.x / Geom<AT>::TPR; }
 
-// XCD-aware remap of a 1-D grid: ids congruent mod 8 share an XCD (observed round-robin
-// dispatch; speed only, never correctness); inside one XCD's sequence consecutive ids walk the
-// column tiles of the same row block, so they share that block's A rows through the XCD's L2.
+// Block id -> tile.  Observed dispatch (speed only, never correctness): ids round-robin over the
+// 8 XCDs; inside an XCD the first 32 blocks take the 32 CUs in order, the next 32 become their
+// co-residents, and a finished block is replaced by the block 64 slots later.
+//   * the column tiles of one row block sit on neighbouring CUs of ONE XCD at the same time, so
+//     they share that row block's A rows through the XCD's L2;
+//   * (GGCN_PAIR_MAP) the two co-resident blocks of a CU work on the SAME column tile of two
+//     neighbouring row blocks, so the second one finds the B fragments in the CU's L1.
 __device__ __forceinline__ bool tile_of_block(int id, int m_tiles, int n_wg, int &m_tile, int &n_wgi)
 {
     const int xcd = id & 7, slot = id >> 3;
+#if defined(GGCN_PAIR_MAP)
+    const int half = (slot >> 5) & 1;
+    const int p = ((slot >> 6) << 5) | (slot & 31);
+    n_wgi = p % n_wg;
+    m_tile = ((p / n_wg) * 2 + half) * 8 + xcd;
+#else
     m_tile = (slot / n_wg) * 8 + xcd;
     n_wgi = slot % n_wg;
+#endif
     return m_tile < m_tiles;
 }
-inline int64_t grid_for(int64_t m_tiles, int n_wg) { return (m_tiles + 7) / 8 * 8 * n_wg; }
+inline int64_t grid_for(int64_t m_tiles, int n_wg)
+{
+    const int64_t per_xcd = (m_tiles + 7) / 8;          // row blocks per XCD
+#if defined(GGCN_PAIR_MAP)
+    const int64_t pairs = (per_xcd + 1) / 2 * n_wg;     // (row-block pair, column tile) items
+    return (pairs + 31) / 32 * 64 * 8;
+#else
+    return per_xcd * n_wg * 8;
+#endif
+}
 
 __device__ __forceinline__ float elem_to_float(float v) { return v; }
 __device__ __forceinline__ float elem_to_float(__half v) { return __half2float(v); }
@@ -219,12 +239,34 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         const int off = a_lds_off(f_row + i * 32, s * 2 + f_half);
         const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(hi_plane + off);
         const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(lo_plane + off);
+#if defined(GGCN_LAB_MFMA16)
+        // TIMING-ONLY experiment (wrong results): same flops as 16x16x32 instructions, to see what
+        // clock the chip holds on that shape (MI355X_MICROARCH.md DVFS item 7)
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 q[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q[t] = f32x4{acc[i][j][4 * t], acc[i][j][4 * t + 1], acc[i][j][4 * t + 2], acc[i][j][4 * t + 3]};
+            q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b[j][0], q[0], 0, 0, 0);
+            q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b[j][0], q[1], 0, 0, 0);
+            q[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b[j][1], q[2], 0, 0, 0);
+            q[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b[j][1], q[3], 0, 0, 0);
+            q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b[j][0], q[0], 0, 0, 0);
+            q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b[j][0], q[1], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * t + e] = q[t][e];
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][1], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][0], acc[i][j], 0, 0, 0);
         }
+#endif
     };
 
 #pragma unroll

@@ -43,6 +43,12 @@ int ggcn_csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t st
                           capacity, rowmask, flags, workspace, as_stream(stream));
 }
 
+int ggcn_rowmask_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t stride_b, int64_t stride_r,
+                            int64_t stride_c, uint32_t *rowmask, int32_t *flags, ggcn_stream_t stream)
+{
+    return rowmask_from_dense(adj, adj_dtype, B, T, stride_b, stride_r, stride_c, rowmask, flags, as_stream(stream));
+}
+
 int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask,
                      ggcn_stream_t stream)
 {

@@ -31,6 +31,8 @@ int csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int
                    int32_t *rowptr, int32_t *colidx, float *vals, int64_t capacity, uint32_t *rowmask,
                    int32_t *flags, void *workspace, hipStream_t st);
 size_t csr_workspace_bytes(int64_t n_rows);
+int rowmask_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int64_t sr, int64_t sc,
+                       uint32_t *rowmask, int32_t *flags, hipStream_t st);
 
 int linear_fp32(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y, int64_t ldy,
                 int64_t M, int K, int F, hipStream_t st);

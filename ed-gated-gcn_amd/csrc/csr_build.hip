@@ -142,6 +142,39 @@ __global__ __launch_bounds__(kScanBlock) void scan_finish(int32_t *__restrict__ 
     }
 }
 
+// Row masks only (T <= 32): one pass over adj, two rows per wavefront (lanes 0-31 / 32-63), the
+// ballot halves ARE the masks.  This is all the fused layer kernel needs from a dense adjacency;
+// the CSR arrays are built only when something asks for them.
+template <typename A>
+__global__ __launch_bounds__(256) void rowmask_rows(const A *__restrict__ adj, int64_t n_rows, int T,
+                                                    int64_t sb, int64_t sr, int64_t sc,
+                                                    uint32_t *__restrict__ rowmask, int32_t *__restrict__ flags)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const int j = lane & 31;
+    float v = 0.0f;
+    if (row < n_rows && j < T) {
+        const int64_t b = row / T;
+        const int i = (int)(row - b * T);
+        v = load_adj<A>(adj + b * sb + (int64_t)i * sr + (int64_t)j * sc);
+    }
+    const unsigned long long m = __ballot(v != 0.0f);
+    if (j == 0 && row < n_rows) rowmask[row] = (uint32_t)(m >> (lane & 32));
+    if (flags && __any(v != 0.0f && v != 1.0f) && lane == 0) atomicOr(flags, GGCN_FLAG_WEIGHTED);
+}
+
+template <typename A>
+int run_mask(const void *adj, int B, int T, int64_t sb, int64_t sr, int64_t sc, uint32_t *rowmask,
+             int32_t *flags, hipStream_t st)
+{
+    const int64_t n = (int64_t)B * T;
+    if (flags) (void)hipMemsetAsync(flags, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL((rowmask_rows<A>), dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st,
+                       static_cast<const A *>(adj), n, T, sb, sr, sc, rowmask, flags);
+    return check_launch("ggcn_rowmask_from_dense");
+}
+
 template <typename A>
 int run(const void *adj, int B, int T, int64_t sb, int64_t sr, int64_t sc, int32_t *rowptr,
         int32_t *colidx, float *vals, int64_t capacity, uint32_t *rowmask, int32_t *flags,
@@ -171,6 +204,23 @@ size_t csr_workspace_bytes(int64_t n_rows)
     if (n_rows < 0) return 0;
     const int64_t tiles = (n_rows + kScanTile - 1) / kScanTile;
     return (size_t)(tiles > 0 ? tiles : 1) * sizeof(int32_t);
+}
+
+int rowmask_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int64_t sr, int64_t sc,
+                       uint32_t *rowmask, int32_t *flags, hipStream_t st)
+{
+    if (!adj || !rowmask) return fail(GGCN_EINVAL, "ggcn_rowmask_from_dense: null pointer");
+    if (B <= 0 || T <= 0) return fail(GGCN_EINVAL, "ggcn_rowmask_from_dense: B=%d T=%d must be positive", B, T);
+    if (T > 32) return fail(GGCN_EUNSUPPORTED, "ggcn_rowmask_from_dense: row masks need T <= 32, got T=%d", T);
+    switch (adj_dtype) {
+        case GGCN_ADJ_F32: return run_mask<float>(adj, B, T, sb, sr, sc, rowmask, flags, st);
+        case GGCN_ADJ_U8: return run_mask<uint8_t>(adj, B, T, sb, sr, sc, rowmask, flags, st);
+        case GGCN_ADJ_I32: return run_mask<int32_t>(adj, B, T, sb, sr, sc, rowmask, flags, st);
+        case GGCN_ADJ_I64: return run_mask<int64_t>(adj, B, T, sb, sr, sc, rowmask, flags, st);
+        case GGCN_ADJ_F64: return run_mask<double>(adj, B, T, sb, sr, sc, rowmask, flags, st);
+        case GGCN_ADJ_F16: return run_mask<__half>(adj, B, T, sb, sr, sc, rowmask, flags, st);
+        default: return fail(GGCN_EINVAL, "ggcn_rowmask_from_dense: unknown adj_dtype %d", adj_dtype);
+    }
 }
 
 int csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int64_t sr, int64_t sc,

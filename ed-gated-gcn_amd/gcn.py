@@ -225,7 +225,7 @@ class GraphConvolution(nn.Module):
                                        % (name, B, F, tuple(g.shape)))
         half = text.dtype == torch.float16
         use_fused = (self.fused and self.precision == "bf16x3" and csr.rowmask is not None
-                     and csr.vals is None and not half)
+                     and csr.is_binary and not half)
         hidden = None if use_fused else self.linear(x2d)
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)

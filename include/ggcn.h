@@ -90,6 +90,12 @@ int ggcn_csr_from_dense(const void *adj, int adj_dtype, int B, int T,
                         uint32_t *rowmask, int32_t *flags,
                         void *workspace, ggcn_stream_t stream);
 
+/* Row masks straight from the dense adjacency (T <= 32): one pass, no CSR arrays.  This is all
+ * ggcn_layer_fused needs, so the drop-in forward(text, adj) builds nothing else. */
+int ggcn_rowmask_from_dense(const void *adj, int adj_dtype, int B, int T,
+                            int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                            uint32_t *rowmask, int32_t *flags, ggcn_stream_t stream);
+
 /* Row masks from an existing batched CSR (T <= 32). */
 int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
                      uint32_t *rowmask, ggcn_stream_t stream);
