@@ -45,6 +45,9 @@ def parse():
                     help="weak: --graphs per GPU; strong: --graphs in total, sharded (BASELINE configs[2])")
     ap.add_argument("--unfused", action="store_true", help="force linear + aggregate (2 launches per layer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to "
+                    "rehearse the N>1 code path on a one-GPU box together with --same-device")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-graphs", type=int, default=4096, help="sample size of the CPU baseline")
     return ap.parse_args()
 
@@ -99,10 +102,13 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", 0 if args.same_device else local)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     pkg.load_library()
     B_total = args.graphs * world if args.scaling == "weak" else args.graphs

@@ -105,7 +105,13 @@ __device__ __forceinline__ void load_f32(const float *p, float (&v)[VEC])
 // NORM = true: the forward (divide by rowsum+1, bias, gates, pools).  NORM = false: the plain
 // weighted sum out[i] = sum_e vals[e] * src_scale[colidx[e]] * Hd[colidx[e]] used by the backward
 // pass (the transposed adjacency applied to D.dY: src_scale = 1/(rowsum+1) of the SOURCE row).
-template <typename E, int VEC, bool HAS_VALS, bool NORM = true>
+// TILED: the graph's T x (64*VEC) slab of Hd is first copied into LDS (every source row read
+// from HBM/L2 exactly once, T <= kTiledMaxT) and the neighbour sum reads LDS.  PMC on the direct
+// form at config 2: 910 MB fetched for 403 MB of Hd -- the ~deg re-reads of a row miss the XCD's
+// 4 MiB L2 half of the time because 256 resident workgroups x 32 KiB of slab exceed it.
+constexpr int kTiledMaxT = 48;  // static 8-16 KiB + 48 KiB of tile stays within the default 64 KiB LDS limit
+
+template <typename E, int VEC, bool HAS_VALS, bool NORM = true, bool TILED = false>
 __global__ __launch_bounds__(256) void aggregate_rows(
     const E *__restrict__ Hd, int64_t ldh, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ colidx, const float *__restrict__ vals,
@@ -117,6 +123,8 @@ __global__ __launch_bounds__(256) void aggregate_rows(
 {
     constexpr int kSlab = kWave * VEC;
     __shared__ float red[2][kWaves][kSlab];
+    extern __shared__ __attribute__((aligned(16))) char tile_raw[];  // TILED: [T][kSlab] of E
+    E *tile = reinterpret_cast<E *>(tile_raw);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -140,73 +148,105 @@ __global__ __launch_bounds__(256) void aggregate_rows(
     }
 
     const E *hcol = Hd + col;
-    for (int t = wave; t < T; t += kWaves) {
-        const int64_t row = (int64_t)b * T + t;
-        const int beg = rowptr[row];
-        const int end = rowptr[row + 1];
-        float acc[VEC];
+    if constexpr (TILED) {
+        // copy phase: wavefront w brings rows w, w+4, ... (one coalesced 1 KiB load each, all in
+        // flight together), then one barrier; raw element type, converted when read back
+        constexpr int kMaxRows = kTiledMaxT / kWaves;
+        float stage[kMaxRows][VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-        float wsum = 0.0f;
-        for (int e = beg; e < end; e += 4) {
-            // wave-uniform neighbour ids / weights: scalar loads
-            const bool v1 = e + 1 < end, v2 = e + 2 < end, v3 = e + 3 < end;
-            const int c0 = colidx[e];
-            const int c1 = v1 ? colidx[e + 1] : c0;
-            const int c2 = v2 ? colidx[e + 2] : c0;
-            const int c3 = v3 ? colidx[e + 3] : c0;
-            float h0[VEC], h1[VEC], h2[VEC], h3[VEC];
+        for (int q = 0; q < kMaxRows; ++q) {
+            const int t = wave + q * kWaves;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) h0[k] = h1[k] = h2[k] = h3[k] = 0.0f;
-            if (live) {  // four independent row-segment reads in flight (1 KiB each per wavefront)
-                Seg<E, VEC>::load(hcol + (int64_t)c0 * ldh, h0);
-                Seg<E, VEC>::load(hcol + (int64_t)c1 * ldh, h1);
-                Seg<E, VEC>::load(hcol + (int64_t)c2 * ldh, h2);
-                Seg<E, VEC>::load(hcol + (int64_t)c3 * ldh, h3);
-            }
-            if constexpr (HAS_VALS || !NORM) {
-                float w0 = HAS_VALS ? vals[e] : 1.0f;
-                float w1 = v1 ? (HAS_VALS ? vals[e + 1] : 1.0f) : 0.0f;
-                float w2 = v2 ? (HAS_VALS ? vals[e + 2] : 1.0f) : 0.0f;
-                float w3 = v3 ? (HAS_VALS ? vals[e + 3] : 1.0f) : 0.0f;
-                if constexpr (!NORM) {
-                    w0 *= src_scale[c0];
-                    w1 *= src_scale[c1];
-                    w2 *= src_scale[c2];
-                    w3 *= src_scale[c3];
+            for (int k = 0; k < VEC; ++k) stage[q][k] = 0.0f;
+            if (t < T && live) Seg<E, VEC>::load(hcol + ((int64_t)b * T + t) * ldh, stage[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < kMaxRows; ++q) {
+            const int t = wave + q * kWaves;
+            if (t < T) Seg<E, VEC>::store(tile + (size_t)t * kSlab + lane * VEC, stage[q]);
+        }
+        __syncthreads();
+    }
+    // Two destination rows per wavefront at a time (t and t+4): their index loads and their 2 x 4
+    // source-row reads are issued together, which halves the dependent-latency chains per row
+    // (rowptr -> colidx -> features) that bound this kernel (measured 217 -> see DESIGN.md).
+    for (int t = wave; t < T; t += 2 * kWaves) {
+        const bool two = t + kWaves < T;  // wave-uniform
+        int64_t row[2];
+        int e[2], end[2], cnt[2];
+        float acc[2][VEC], wsum[2];
+        row[0] = (int64_t)b * T + t;
+        row[1] = two ? row[0] + kWaves : row[0];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            e[r] = rowptr[row[r]];
+            end[r] = rowptr[row[r] + 1];
+            cnt[r] = end[r] - e[r];
+            wsum[r] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[r][k] = 0.0f;
+        }
+        if (!two) end[1] = e[1];  // no second row: zero trips
+        while (e[0] < end[0] || e[1] < end[1]) {
+            int c[2][4];
+            bool v[2][4];
+            float w[2][4];
+            float h[2][4][VEC];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {  // wave-uniform neighbour ids / weights: scalar loads
+                    v[r][q] = e[r] + q < end[r];
+                    c[r][q] = colidx[v[r][q] ? e[r] + q : 0];
+                    w[r][q] = 1.0f;
+                    if constexpr (HAS_VALS) w[r][q] = vals[v[r][q] ? e[r] + q : 0];
+                    if constexpr (!NORM) w[r][q] *= src_scale[c[r][q]];
                 }
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {  // a masked-out neighbour must not contribute 0*inf
-                    acc[k] = fmaf(w0, h0[k], acc[k]);
-                    if (v1) acc[k] = fmaf(w1, h1[k], acc[k]);
-                    if (v2) acc[k] = fmaf(w2, h2[k], acc[k]);
-                    if (v3) acc[k] = fmaf(w3, h3[k], acc[k]);
-                }
-                wsum += w0;
-                wsum += w1;
-                wsum += w2;
-                wsum += w3;
-            } else {
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    acc[k] += h0[k];
-                    if (v1) acc[k] += h1[k];
-                    if (v2) acc[k] += h2[k];
-                    if (v3) acc[k] += h3[k];
+                for (int q = 0; q < 4; ++q) {  // 8 independent row-segment reads in flight per wavefront
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) h[r][q][k] = 0.0f;
+                    if constexpr (TILED) {
+                        if (v[r][q]) Seg<E, VEC>::load(tile + (size_t)(c[r][q] - b * T) * kSlab + lane * VEC, h[r][q]);
+                    } else {
+                        if (live && v[r][q]) Seg<E, VEC>::load(hcol + (int64_t)c[r][q] * ldh, h[r][q]);
+                    }
                 }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (v[r][q]) {  // wave-uniform; a masked-out neighbour must not contribute 0*inf
+                        if constexpr (HAS_VALS || !NORM) {
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) acc[r][k] = fmaf(w[r][q], h[r][q][k], acc[r][k]);
+                            wsum[r] += w[r][q];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) acc[r][k] += h[r][q][k];
+                        }
+                    }
+                }
+                e[r] += 4;
             }
         }
-        const float denom = NORM ? (HAS_VALS ? wsum : (float)(end - beg)) + 1.0f : 1.0f;  // gcn.py:35
-        if (live) {
-            float y[VEC], o[VEC];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                y[k] = NORM ? acc[k] / denom + vb[k] : acc[k];  // gcn.py:41,43; IEEE division like torch's `/`
-                o[k] = y[k] * vsg[k];
-                pa[k] = fmaxf(pa[k], y[k] * vga[k]);
-                pb[k] = fmaxf(pb[k], y[k] * vgb[k]);
+        for (int r = 0; r < 2; ++r) {
+            if (r == 1 && !two) break;
+            const float denom = NORM ? (HAS_VALS ? wsum[r] : (float)cnt[r]) + 1.0f : 1.0f;  // gcn.py:35
+            if (live) {
+                float y[VEC], o[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    y[k] = NORM ? acc[r][k] / denom + vb[k] : acc[r][k];  // gcn.py:41,43; IEEE division like torch's `/`
+                    o[k] = y[k] * vsg[k];
+                    pa[k] = fmaxf(pa[k], y[k] * vga[k]);
+                    pb[k] = fmaxf(pb[k], y[k] * vgb[k]);
+                }
+                if (out) Seg<E, VEC>::store(out + row[r] * ldo + col, o);
             }
-            if (out) Seg<E, VEC>::store(out + row * ldo + col, o);
         }
     }
 
@@ -242,12 +282,16 @@ int launch(const E *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colid
     const int n_slabs = (F + slab - 1) / slab;
     const int64_t blocks = (int64_t)B * n_slabs;
     if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_aggregate: grid too large");
-    if (vals)
-        hipLaunchKernelGGL((aggregate_rows<E, VEC, true>), dim3((unsigned)blocks), dim3(256), 0, st, Hd, ldh,
-                           rowptr, colidx, vals, nullptr, bias, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb);
-    else
-        hipLaunchKernelGGL((aggregate_rows<E, VEC, false>), dim3((unsigned)blocks), dim3(256), 0, st, Hd, ldh,
-                           rowptr, colidx, vals, nullptr, bias, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb);
+    const bool tiled = (VEC > 1) && (T <= kTiledMaxT);
+    const size_t lds = tiled ? (size_t)T * slab * sizeof(E) : 0;
+#define GGCN_AGG(HV, TL)                                                                                      \
+    hipLaunchKernelGGL((aggregate_rows<E, VEC, HV, true, TL>), dim3((unsigned)blocks), dim3(256), lds, st, Hd, \
+                       ldh, rowptr, colidx, vals, nullptr, bias, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb)
+    if (vals && tiled) GGCN_AGG(true, true);
+    else if (vals) GGCN_AGG(true, false);
+    else if (tiled) GGCN_AGG(false, true);
+    else GGCN_AGG(false, false);
+#undef GGCN_AGG
     return check_launch("ggcn_aggregate");
 }
 
@@ -259,14 +303,17 @@ int launch_t(const float *G, int64_t ldg, const int32_t *rowptr, const int32_t *
     const int n_slabs = (F + slab - 1) / slab;
     const int64_t blocks = (int64_t)B * n_slabs;
     if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_aggregate_t: grid too large");
-    if (vals)
-        hipLaunchKernelGGL((aggregate_rows<float, VEC, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, G,
-                           ldg, rowptr, colidx, vals, src_scale, nullptr, T, F, n_slabs, nullptr, nullptr, nullptr,
-                           out, ldo, nullptr, nullptr);
-    else
-        hipLaunchKernelGGL((aggregate_rows<float, VEC, false, false>), dim3((unsigned)blocks), dim3(256), 0, st, G,
-                           ldg, rowptr, colidx, vals, src_scale, nullptr, T, F, n_slabs, nullptr, nullptr, nullptr,
-                           out, ldo, nullptr, nullptr);
+    const bool tiled = (VEC > 1) && (T <= kTiledMaxT);
+    const size_t lds = tiled ? (size_t)T * slab * sizeof(float) : 0;
+#define GGCN_AGGT(HV, TL)                                                                                        \
+    hipLaunchKernelGGL((aggregate_rows<float, VEC, HV, false, TL>), dim3((unsigned)blocks), dim3(256), lds, st, G, \
+                       ldg, rowptr, colidx, vals, src_scale, nullptr, T, F, n_slabs, nullptr, nullptr, nullptr,     \
+                       out, ldo, nullptr, nullptr)
+    if (vals && tiled) GGCN_AGGT(true, true);
+    else if (vals) GGCN_AGGT(true, false);
+    else if (tiled) GGCN_AGGT(false, true);
+    else GGCN_AGGT(false, false);
+#undef GGCN_AGGT
     return check_launch("ggcn_aggregate_t");
 }
 
