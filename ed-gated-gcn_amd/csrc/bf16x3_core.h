@@ -108,8 +108,14 @@ template <typename AT>
 __device__ __forceinline__ void load16(const AT *p, float (&v)[Geom<AT>::EPT])
 {
     if constexpr (sizeof(AT) == 4) {
+#if defined(GGCN_A_NT)
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const f32x4v t = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(p));
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+#else
         const float4 t = *reinterpret_cast<const float4 *>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+#endif
     } else {
         const uint4 t = *reinterpret_cast<const uint4 *>(p);
         const __half2 *h = reinterpret_cast<const __half2 *>(&t);

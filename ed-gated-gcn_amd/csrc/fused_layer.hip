@@ -51,9 +51,22 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
     const float *__restrict__ pool_gate_b, float *__restrict__ out, int ldo,
     float *__restrict__ pool_a, float *__restrict__ pool_b, int g_tiles, int n_wg, int k_steps)
 {
+#if defined(GGCN_LAB_LDS_PAD)
+    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes + GGCN_LAB_LDS_PAD];  // occupancy experiment
+#else
     __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+#endif
     int g_tile, n_wgi;
     if (!tile_of_block(blockIdx.x, g_tiles, n_wg, g_tile, n_wgi)) return;
+#if defined(GGCN_STAGGER)
+    // Two workgroups share a CU and run the same program; started together they stay in lockstep
+    // and reach their (MFMA-free) epilogues at the same time.  Delay the second resident set of the
+    // initial dispatch by about half a tile once: every later block inherits its slot's phase.
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll 1
+        for (int i = 0; i < GGCN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
