@@ -85,6 +85,14 @@ struct Seg<__half, 1> {
     static __device__ __forceinline__ void store(__half *p, const float (&v)[1]) { *p = __float2half_rn(v[0]); }
 };
 
+// max for floats through integer atomics (order-independent, hence deterministic): non-negative
+// values order like signed ints, negative ones like unsigned ints reversed.  -inf is the identity.
+__device__ __forceinline__ void atomic_max_float(float *p, float v)
+{
+    if (v >= 0.0f) atomicMax(reinterpret_cast<int *>(p), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned int *>(p), __float_as_uint(v));
+}
+
 template <int VEC>
 __device__ __forceinline__ void load_f32(const float *p, float (&v)[VEC])
 {
@@ -109,6 +117,7 @@ __device__ __forceinline__ void load_f32(const float *p, float (&v)[VEC])
 // from HBM/L2 exactly once, T <= kTiledMaxT) and the neighbour sum reads LDS.  PMC on the direct
 // form at config 2: 910 MB fetched for 403 MB of Hd -- the ~deg re-reads of a row miss the XCD's
 // 4 MiB L2 half of the time because 256 resident workgroups x 32 KiB of slab exceed it.
+constexpr int kChunkRows = 16;   // destination rows per workgroup when a graph is cut into chunks
 constexpr int kTiledMaxT = 48;  // static 8-16 KiB + 48 KiB of tile stays within the default 64 KiB LDS limit
 
 template <typename E, int VEC, bool HAS_VALS, bool NORM = true, bool TILED = false>
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(
     const E *__restrict__ Hd, int64_t ldh, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ colidx, const float *__restrict__ vals,
     const float *__restrict__ src_scale,
-    const float *__restrict__ bias, int T, int F, int n_slabs,
+    const float *__restrict__ bias, int n_graphs, int T, int F, int n_slabs, int n_chunks, int chunk_rows,
     const float *__restrict__ store_gate, const float *__restrict__ pool_gate_a,
     const float *__restrict__ pool_gate_b, E *__restrict__ out, int64_t ldo,
     float *__restrict__ pool_a, float *__restrict__ pool_b)
@@ -128,8 +137,27 @@ __global__ __launch_bounds__(256) void aggregate_rows(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x / n_slabs;
-    const int slab = blockIdx.x - b * n_slabs;
+    // block -> (graph b, row chunk, column slab).  Long graphs (T > kTiledMaxT) are cut into
+    // chunks of chunk_rows destination rows so that 256 x 512-token graphs still fill the chip
+    // (BASELINE configs[3]); the pooled max of a chunked graph is combined with atomics.
+    const int per_graph = n_slabs * n_chunks;
+    int b, rem;
+    if (n_chunks == 1) {
+        b = blockIdx.x / per_graph;
+        rem = blockIdx.x - b * per_graph;
+    } else {
+        // XCD-affine order (ids congruent mod 8 share an XCD, observed dispatch; speed only): an
+        // XCD walks through ITS graphs one after the other, all pieces of a graph back to back, so
+        // only a few graphs' feature blocks (T x F, 1-2 MiB at config 4) compete for its 4 MiB L2.
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b = (slot / per_graph) * 8 + xcd;
+        rem = slot % per_graph;
+        if (b >= n_graphs) return;  // whole workgroup, before any barrier
+    }
+    const int chunk = rem % n_chunks;       // chunk fastest: the chunks of one column slab share rows
+    const int slab = rem / n_chunks;
+    const int t_begin = chunk * chunk_rows;
+    const int t_end = (t_begin + chunk_rows < T) ? t_begin + chunk_rows : T;
     const int col = slab * kSlab + lane * VEC;
     const bool live = col < F;  // F % VEC == 0 is checked on the host
 
@@ -170,8 +198,8 @@ __global__ __launch_bounds__(256) void aggregate_rows(
     // Two destination rows per wavefront at a time (t and t+4): their index loads and their 2 x 4
     // source-row reads are issued together, which halves the dependent-latency chains per row
     // (rowptr -> colidx -> features) that bound this kernel (measured 217 -> see DESIGN.md).
-    for (int t = wave; t < T; t += 2 * kWaves) {
-        const bool two = t + kWaves < T;  // wave-uniform
+    for (int t = t_begin + wave; t < t_end; t += 2 * kWaves) {
+        const bool two = t + kWaves < t_end;  // wave-uniform
         int64_t row[2];
         int e[2], end[2], cnt[2];
         float acc[2][VEC], wsum[2];
@@ -235,12 +263,14 @@ __global__ __launch_bounds__(256) void aggregate_rows(
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             if (r == 1 && !two) break;
-            const float denom = NORM ? (HAS_VALS ? wsum[r] : (float)cnt[r]) + 1.0f : 1.0f;  // gcn.py:35
+            // gcn.py:35,41: divide by rowsum+1 -- one IEEE reciprocal per row (the denominator is
+            // wave-uniform), then a multiply per element: <= 1 ulp from the reference's division
+            const float inv = NORM ? 1.0f / ((HAS_VALS ? wsum[r] : (float)cnt[r]) + 1.0f) : 1.0f;
             if (live) {
                 float y[VEC], o[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    y[k] = NORM ? acc[r][k] / denom + vb[k] : acc[r][k];  // gcn.py:41,43; IEEE division like torch's `/`
+                    y[k] = NORM ? acc[r][k] * inv + vb[k] : acc[r][k];  // gcn.py:41,43
                     o[k] = y[k] * vsg[k];
                     pa[k] = fmaxf(pa[k], y[k] * vga[k]);
                     pb[k] = fmaxf(pb[k], y[k] * vgb[k]);
@@ -266,8 +296,13 @@ __global__ __launch_bounds__(256) void aggregate_rows(
                 ma = fmaxf(ma, red[0][w][tl]);
                 mb = fmaxf(mb, red[1][w][tl]);
             }
-            if (pool_a) pool_a[(int64_t)b * F + tcol] = ma;
-            if (pool_b) pool_b[(int64_t)b * F + tcol] = mb;
+            if (n_chunks == 1) {
+                if (pool_a) pool_a[(int64_t)b * F + tcol] = ma;
+                if (pool_b) pool_b[(int64_t)b * F + tcol] = mb;
+            } else {  // pools were preset to -inf by the launcher
+                if (pool_a) atomic_max_float(pool_a + (int64_t)b * F + tcol, ma);
+                if (pool_b) atomic_max_float(pool_b + (int64_t)b * F + tcol, mb);
+            }
         }
     }
 }
@@ -280,13 +315,22 @@ int launch(const E *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colid
 {
     const int slab = kWave * VEC;
     const int n_slabs = (F + slab - 1) / slab;
-    const int64_t blocks = (int64_t)B * n_slabs;
-    if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_aggregate: grid too large");
     const bool tiled = (VEC > 1) && (T <= kTiledMaxT);
+    const int chunk_rows = tiled ? T : kChunkRows;
+    const int n_chunks = tiled ? 1 : (T + kChunkRows - 1) / kChunkRows;
+    const int64_t blocks = (n_chunks == 1 ? (int64_t)B : ((int64_t)B + 7) / 8 * 8) * n_slabs * n_chunks;
+    if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_aggregate: grid too large");
+    if (n_chunks > 1) {  // -inf = 0xFF800000: identity of the atomic max (a memset node, graph-capturable)
+        if (pa && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(pa), (int)0xFF800000, (size_t)B * F, st) != hipSuccess)
+            return fail(GGCN_ELAUNCH, "ggcn_aggregate: pool preset failed");
+        if (pb && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(pb), (int)0xFF800000, (size_t)B * F, st) != hipSuccess)
+            return fail(GGCN_ELAUNCH, "ggcn_aggregate: pool preset failed");
+    }
     const size_t lds = tiled ? (size_t)T * slab * sizeof(E) : 0;
 #define GGCN_AGG(HV, TL)                                                                                      \
     hipLaunchKernelGGL((aggregate_rows<E, VEC, HV, true, TL>), dim3((unsigned)blocks), dim3(256), lds, st, Hd, \
-                       ldh, rowptr, colidx, vals, nullptr, bias, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb)
+                       ldh, rowptr, colidx, vals, nullptr, bias, B, T, F, n_slabs, n_chunks, chunk_rows, sg, ga, \
+                       gb, out, ldo, pa, pb)
     if (vals && tiled) GGCN_AGG(true, true);
     else if (vals) GGCN_AGG(true, false);
     else if (tiled) GGCN_AGG(false, true);
@@ -301,14 +345,16 @@ int launch_t(const float *G, int64_t ldg, const int32_t *rowptr, const int32_t *
 {
     const int slab = kWave * VEC;
     const int n_slabs = (F + slab - 1) / slab;
-    const int64_t blocks = (int64_t)B * n_slabs;
-    if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_aggregate_t: grid too large");
     const bool tiled = (VEC > 1) && (T <= kTiledMaxT);
+    const int chunk_rows = tiled ? T : kChunkRows;
+    const int n_chunks = tiled ? 1 : (T + kChunkRows - 1) / kChunkRows;
+    const int64_t blocks = (n_chunks == 1 ? (int64_t)B : ((int64_t)B + 7) / 8 * 8) * n_slabs * n_chunks;
+    if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_aggregate_t: grid too large");
     const size_t lds = tiled ? (size_t)T * slab * sizeof(float) : 0;
 #define GGCN_AGGT(HV, TL)                                                                                        \
     hipLaunchKernelGGL((aggregate_rows<float, VEC, HV, false, TL>), dim3((unsigned)blocks), dim3(256), lds, st, G, \
-                       ldg, rowptr, colidx, vals, src_scale, nullptr, T, F, n_slabs, nullptr, nullptr, nullptr,     \
-                       out, ldo, nullptr, nullptr)
+                       ldg, rowptr, colidx, vals, src_scale, nullptr, B, T, F, n_slabs, n_chunks, chunk_rows, nullptr, \
+                       nullptr, nullptr, out, ldo, nullptr, nullptr)
     if (vals && tiled) GGCN_AGGT(true, true);
     else if (vals) GGCN_AGGT(true, false);
     else if (tiled) GGCN_AGGT(false, true);
