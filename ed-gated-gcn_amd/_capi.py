@@ -29,6 +29,10 @@ PROTOTYPES = {
     "ggcn_linear": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "ggcn_gate_pool_backward": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                        c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "ggcn_dweight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
+    "ggcn_dweight": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "ggcn_weight_pack_t": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_inv_denominators": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "ggcn_aggregate_t": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),

@@ -136,6 +136,23 @@ int ggcn_aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const i
                        ldo, pool_a, pool_b, as_stream(stream));
 }
 
+int ggcn_gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
+                            const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
+                            const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
+                            float *d_ga, float *d_gb, ggcn_stream_t stream)
+{
+    return gate_pool_backward(out, ldo, store_gate, gate_a, gate_b, d_out, ldd, d_pa, d_pb, B, T, F, dY, ldy, d_sg,
+                              d_ga, d_gb, as_stream(stream));
+}
+
+size_t ggcn_dweight_workspace_bytes(int64_t n_rows, int K, int F) { return dweight_workspace_bytes(n_rows, K, F); }
+
+int ggcn_dweight(const float *X, int64_t ldx, const float *dH, int64_t ldg, int64_t n_rows, int K, int F,
+                 float *dW, int64_t lddw, void *workspace, ggcn_stream_t stream)
+{
+    return dweight(X, ldx, dH, ldg, n_rows, K, F, dW, lddw, workspace, as_stream(stream));
+}
+
 size_t ggcn_overlap_workspace_bytes(int B) { return overlap_workspace_bytes(B); }
 
 int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,

@@ -62,6 +62,15 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b, hipStream_t st);
 
+int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
+                       const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
+                       const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
+                       float *d_ga, float *d_gb, hipStream_t st);
+
+size_t dweight_workspace_bytes(int64_t N, int K, int F);
+int dweight(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F, float *dW,
+            int64_t lddw, void *workspace, hipStream_t st);
+
 size_t overlap_workspace_bytes(int B);
 int gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,
                  hipStream_t st);

@@ -1,0 +1,78 @@
+// Backward of the gate / max-pool epilogue of one layer (models/bert_amir5.py:627-640 under
+// train.py:120 `loss.backward()`), in ONE pass over the stored layer output.
+//
+// Forward (per graph g, feature f; y = the ungated layer output of gcn.py:45):
+//     out[t]  = y[t] * sg          pa = max_t y[t] * ga          pb = max_t y[t] * gb
+// Given d_out [N,F] (optional), d_pa, d_pb [B,F] (optional):
+//     dY[t]   = d_out[t]*sg + [t = argmax_a] d_pa*ga + [t = argmax_b] d_pb*gb
+//     d_sg    = sum_t d_out[t]*y[t]      d_ga = d_pa * y[argmax_a]      d_gb = d_pb * y[argmax_b]
+// y is recovered as out/sg when a store gate was applied (sigmoid gates are > 0; sg == 0 -> y := 0),
+// argmax = the FIRST row attaining the maximum of y*g (torch.max's choice, bert_amir5.py:635).
+// Mapping: workgroup = (graph, 256-column slab), thread = one column, loop over the T rows twice
+// (find the maxima, then write dY): coalesced 1 KiB row segments, HBM-bound:
+// 4*N*F (out) [+ 4*N*F d_out] read, 4*N*F (dY) written.
+#include "common.h"
+
+namespace ggcn {
+namespace {
+
+__global__ __launch_bounds__(256) void gate_pool_backward_kernel(
+    const float *__restrict__ out, int64_t ldo, const float *__restrict__ store_gate,
+    const float *__restrict__ gate_a, const float *__restrict__ gate_b,
+    const float *__restrict__ d_out, int64_t ldd, const float *__restrict__ d_pa,
+    const float *__restrict__ d_pb, int T, int F, int n_slabs, float *__restrict__ dY, int64_t ldy,
+    float *__restrict__ d_sg, float *__restrict__ d_ga, float *__restrict__ d_gb)
+{
+    const int b = blockIdx.x / n_slabs;
+    const int f = (blockIdx.x - b * n_slabs) * 256 + threadIdx.x;
+    if (f >= F) return;
+    const int64_t gf = (int64_t)b * F + f;
+    const float sg = store_gate ? store_gate[gf] : 1.0f;
+    const float inv_sg = store_gate ? (sg != 0.0f ? 1.0f / sg : 0.0f) : 1.0f;
+    const float ga = gate_a ? gate_a[gf] : 1.0f;
+    const float gb = gate_b ? gate_b[gf] : 1.0f;
+    const float dpa = d_pa ? d_pa[gf] : 0.0f;
+    const float dpb = d_pb ? d_pb[gf] : 0.0f;
+    const float *o = out + (int64_t)b * T * ldo + f;
+
+    float best_a = -INFINITY, best_b = -INFINITY, ya = 0.0f, yb = 0.0f, acc_sg = 0.0f;
+    int ia = 0, ib = 0;
+    for (int t = 0; t < T; ++t) {
+        const float y = o[(int64_t)t * ldo] * inv_sg;
+        const float va = y * ga, vb = y * gb;
+        if (va > best_a) { best_a = va; ia = t; ya = y; }
+        if (vb > best_b) { best_b = vb; ib = t; yb = y; }
+        if (d_out) acc_sg = fmaf(d_out[((int64_t)b * T + t) * ldd + f], y, acc_sg);
+    }
+    for (int t = 0; t < T; ++t) {
+        float g = d_out ? d_out[((int64_t)b * T + t) * ldd + f] * sg : 0.0f;
+        if (d_pa && t == ia) g = fmaf(dpa, ga, g);
+        if (d_pb && t == ib) g = fmaf(dpb, gb, g);
+        dY[((int64_t)b * T + t) * ldy + f] = g;
+    }
+    if (d_sg) d_sg[gf] = acc_sg;
+    if (d_ga) d_ga[gf] = dpa * ya;
+    if (d_gb) d_gb[gf] = dpb * yb;
+}
+
+}  // namespace
+
+int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
+                       const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
+                       const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
+                       float *d_ga, float *d_gb, hipStream_t st)
+{
+    if (!out || !dY) return fail(GGCN_EINVAL, "ggcn_gate_pool_backward: null pointer");
+    if (B <= 0 || T <= 0 || F <= 0)
+        return fail(GGCN_EINVAL, "ggcn_gate_pool_backward: B=%d T=%d F=%d must be positive", B, T, F);
+    if (ldo < F || ldy < F || (d_out && ldd < F))
+        return fail(GGCN_EINVAL, "ggcn_gate_pool_backward: leading dimension smaller than F=%d", F);
+    const int n_slabs = (F + 255) / 256;
+    const int64_t blocks = (int64_t)B * n_slabs;
+    if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_gate_pool_backward: grid too large");
+    hipLaunchKernelGGL(gate_pool_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, ldo, store_gate,
+                       gate_a, gate_b, d_out, ldd, d_pa, d_pb, T, F, n_slabs, dY, ldy, d_sg, d_ga, d_gb);
+    return check_launch("ggcn_gate_pool_backward");
+}
+
+}  // namespace ggcn

@@ -30,45 +30,69 @@ def _require_gpu_f32(name, t, allow_half=False):
         raise RuntimeError("%s must be float32%s, got %s" % (name, " or float16" if allow_half else "", t.dtype))
 
 
-class _GraphConvFunction(torch.autograd.Function):
-    """Y = D.A.(X.W) + b with the backward of ``train.py:115-121`` (autograd through gc1/gc2):
+class _GatedLayerFunction(torch.autograd.Function):
+    """One gated layer under autograd (``train.py:115-121`` trains through gc1/gc2 and the gates).
 
-        dH = A^T.(D.dY)   HIP, one wavefront per SOURCE node on the transposed CSR
-        dX = dH.W^T       HIP bf16x3 MFMA linear on the packed W^T
-        dW = X^T.dH       plain library GEMM (rocBLAS through torch.matmul)
+    Forward = the inference kernels (fused layer or linear + aggregate, gate and max-pool in the
+    epilogue).  Backward, for y = D.A.(X.W) + b, out = y*sg, pa = max_t y*ga, pb = max_t y*gb:
+
+        dY, d_sg, d_ga, d_gb   HIP, one pass over the stored output (gate_pool_backward.hip)
+        dH = A^T.(D.dY)        HIP, one wavefront per SOURCE node on the transposed CSR
+        dX = dH.W^T            HIP bf16x3 MFMA linear on the packed W^T
+        dW = X^T.dH            HIP exact-fp32 MFMA, split over the node rows (dweight_fp32.hip)
         db = sum_rows dY
     """
 
     @staticmethod
-    def forward(ctx, text, weight, bias, layer, csr):
+    def forward(ctx, text, weight, bias, store_gate, gate_a, gate_b, layer, csr, want_pa, want_pb):
         with torch.no_grad():
-            out, _, _ = layer._forward_impl(text, csr)
+            out, pa, pb = layer.forward_gated(text, csr, store_gate=store_gate, pool_gate_a=gate_a,
+                                              pool_gate_b=gate_b, want_out=True, want_pool_a=want_pa,
+                                              want_pool_b=want_pb, _internal=True)
         ctx.layer, ctx.csr = layer, csr
-        ctx.save_for_backward(text, weight)
+        ctx.save_for_backward(text, weight, out, store_gate, gate_a, gate_b)
         ctx.has_bias = bias is not None
-        return out
+        for t in (pa, pb):
+            if t is None:
+                continue
+        return out, pa, pb
 
     @staticmethod
-    def backward(ctx, dy):
-        text, weight = ctx.saved_tensors
+    def backward(ctx, d_out, d_pa, d_pb):
+        text, weight, out, store_gate, gate_a, gate_b = ctx.saved_tensors
         layer, csr = ctx.layer, ctx.csr
         lib = _capi.load_library()
         B, T, K = text.shape
         F = layer.out_features
         dev = text.device
-        dy2 = dy.reshape(B * T, F)
-        if dy2.dtype != torch.float32 or dy2.stride(1) != 1:
-            dy2 = dy2.float().contiguous()
+
+        def f32c(t, shape):
+            if t is None:
+                return None
+            t = t.reshape(shape)
+            return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+        d_out2, d_pa, d_pb = f32c(d_out, (B * T, F)), f32c(d_pa, (B, F)), f32c(d_pb, (B, F))
+        out2 = out.reshape(B * T, F)
         csr_t = csr.transposed()
         inv = csr.inv_denominators()
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
+            dy = torch.empty(B * T, F, dtype=torch.float32, device=dev)
+            need = ctx.needs_input_grad
+            d_sg = torch.empty(B, F, dtype=torch.float32, device=dev) if (store_gate is not None and need[3]) else None
+            d_ga = torch.empty(B, F, dtype=torch.float32, device=dev) if (gate_a is not None and need[4] and d_pa is not None) else None
+            d_gb = torch.empty(B, F, dtype=torch.float32, device=dev) if (gate_b is not None and need[5] and d_pb is not None) else None
+            _capi.check(lib.ggcn_gate_pool_backward(
+                _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),
+                _capi.ptr(d_out2), F, _capi.ptr(d_pa), _capi.ptr(d_pb), B, T, F, _capi.ptr(dy), F,
+                _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), st), "ggcn_gate_pool_backward")
             dh = torch.empty(B * T, F, dtype=torch.float32, device=dev)
-            _capi.check(lib.ggcn_aggregate_t(_capi.ptr(dy2), dy2.stride(0), _capi.ptr(csr_t.rowptr),
-                                             _capi.ptr(csr_t.colidx), _capi.ptr(csr_t.vals), _capi.ptr(inv),
-                                             B, T, F, _capi.ptr(dh), F, st), "ggcn_aggregate_t")
+            _capi.check(lib.ggcn_aggregate_t(_capi.ptr(dy), F, _capi.ptr(csr_t.rowptr), _capi.ptr(csr_t.colidx),
+                                             _capi.ptr(csr_t.vals), _capi.ptr(inv), B, T, F, _capi.ptr(dh), F, st),
+                        "ggcn_aggregate_t")
             dx = dw = db = None
-            if ctx.needs_input_grad[0]:
+            if need[0]:
                 dx = torch.empty(B * T, K, dtype=torch.float32, device=dev)
                 if layer.precision == "bf16x3":
                     pack_t = layer._packed_weight(lib, st, transposed=True)
@@ -79,11 +103,18 @@ class _GraphConvFunction(torch.autograd.Function):
                     _capi.check(lib.ggcn_linear(_capi.ptr(dh), F, _capi.ptr(wt), K, None, _capi.ptr(dx), K,
                                                 B * T, F, K, _capi.PREC["fp32"], st), "ggcn_linear(dX)")
                 dx = dx.view(B, T, K)
-            if ctx.needs_input_grad[1]:
-                dw = text.reshape(B * T, K).t().matmul(dh)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = dy2.sum(dim=0)
-        return dx, dw, db, None, None
+            if need[1]:
+                x2d = text.reshape(B * T, K)
+                if x2d.stride(1) == 1 and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0:
+                    dw = torch.empty(K, F, dtype=torch.float32, device=dev)
+                    ws = torch.empty(lib.ggcn_dweight_workspace_bytes(B * T, K, F), dtype=torch.uint8, device=dev)
+                    _capi.check(lib.ggcn_dweight(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(dh), F, B * T, K, F,
+                                                 _capi.ptr(dw), F, _capi.ptr(ws), st), "ggcn_dweight")
+                else:  # odd strides: plain library GEMM
+                    dw = x2d.t().matmul(dh)
+            if ctx.has_bias and need[2]:
+                db = dy.sum(dim=0)
+        return dx, dw, db, d_sg, d_ga, d_gb, None, None, None, None
 
 
 class GraphConvolution(nn.Module):
@@ -180,12 +211,10 @@ class GraphConvolution(nn.Module):
                         "ggcn_linear")
         return y
 
-    def _needs_grad(self, text):
+    def _needs_grad(self, text, *gates):
         return torch.is_grad_enabled() and (text.requires_grad or self.weight.requires_grad
-                                            or (self.bias is not None and self.bias.requires_grad))
-
-    def _forward_impl(self, text, csr):
-        return self.forward_gated(text, csr, _internal=True)
+                                            or (self.bias is not None and self.bias.requires_grad)
+                                            or any(g is not None and g.requires_grad for g in gates))
 
     def forward_gated(self, text, adj, store_gate=None, pool_gate_a=None, pool_gate_b=None,
                       want_out=True, want_pool_a=False, want_pool_b=False, _internal=False):
@@ -196,20 +225,13 @@ class GraphConvolution(nn.Module):
         plain layer output.  Gates are ``[B,F]`` (broadcast over tokens)."""
         self._check(text)
         csr = self._as_csr(adj, text)
-        if not _internal and self._needs_grad(text):
-            # training: autograd through the layer itself; gate and max-pool as differentiable
-            # torch ops on its output, exactly as the reference writes them (bert_amir5.py:627-640)
+        if not _internal and self._needs_grad(text, store_gate, pool_gate_a, pool_gate_b):
+            # training: the same kernels, wrapped in an autograd Function with a HIP backward
             if text.dtype != torch.float32:
                 raise RuntimeError("training through the HIP layer needs float32 features")
-            y = _GraphConvFunction.apply(text, self.weight, self.bias, self, csr)
-            out = pa = pb = None
-            if want_out:
-                out = y if store_gate is None else y * store_gate[:, None, :]
-            if want_pool_a:
-                pa = (y if pool_gate_a is None else y * pool_gate_a[:, None, :]).max(dim=1)[0]
-            if want_pool_b:
-                pb = (y if pool_gate_b is None else y * pool_gate_b[:, None, :]).max(dim=1)[0]
-            return out, pa, pb
+            out, pa, pb = _GatedLayerFunction.apply(text, self.weight, self.bias, store_gate, pool_gate_a,
+                                                    pool_gate_b, self, csr, want_pool_a, want_pool_b)
+            return (out if want_out else None), pa, pb
         lib = _capi.load_library()
         B, T, _ = text.shape
         F = self.out_features

@@ -138,7 +138,23 @@ int ggcn_aggregate(const float *Hd, int64_t ldh,
  *   dX = dH.W^T       ggcn_linear with the image made by ggcn_weight_pack_t
  *                     (packs the transpose of the stored [K_stored x ldw] matrix: the packed
  *                     operand has K = F_layer rows and F = K_layer columns)
- *   dW = X^T.dH, db = sum_rows dY   plain library GEMM / reduction on the caller's side. */
+ *   dW = X^T.dH       ggcn_dweight: exact fp32 MFMA, split over the node rows, deterministic
+ *                     (workspace: ggcn_dweight_workspace_bytes(N, K, F) bytes)
+ *   db = sum_rows dY  a plain column sum on the caller's side. */
+/* Backward of the gate / max-pool epilogue (models/bert_amir5.py:627-640): from the stored
+ * layer output `out` (= y*store_gate), the gates and the upstream gradients of out and of the
+ * two pooled outputs, produce dY (gradient of the ungated layer output y) and the gate gradients:
+ *   dY[t] = d_out[t]*sg + [t=argmax_a] d_pa*ga + [t=argmax_b] d_pb*gb
+ *   d_sg = sum_t d_out*y,  d_ga = d_pa*y[argmax_a],  d_gb = d_pb*y[argmax_b]
+ * Any of store_gate, gate_a/d_pa, gate_b/d_pb, d_out, d_sg, d_ga, d_gb may be NULL. */
+int ggcn_gate_pool_backward(const float *out, int64_t ldo,
+                            const float *store_gate, const float *gate_a, const float *gate_b,
+                            const float *d_out, int64_t ldd, const float *d_pa, const float *d_pb,
+                            int B, int T, int F, float *dY, int64_t ldy,
+                            float *d_sg, float *d_ga, float *d_gb, ggcn_stream_t stream);
+size_t ggcn_dweight_workspace_bytes(int64_t n_rows, int K, int F);
+int ggcn_dweight(const float *X, int64_t ldx, const float *dH, int64_t ldg, int64_t n_rows, int K, int F,
+                 float *dW, int64_t lddw, void *workspace, ggcn_stream_t stream);
 int ggcn_weight_pack_t(const float *W, int64_t ldw, int K, int F, void *wpack, ggcn_stream_t stream);
 int ggcn_inv_denominators(const int32_t *rowptr, const float *vals, int64_t n_rows, float *inv,
                           ggcn_stream_t stream);
