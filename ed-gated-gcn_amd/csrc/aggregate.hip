@@ -80,6 +80,24 @@ struct Seg<__half, 8> {
     }
 };
 template <>
+struct Seg<__half, 4> {  // 8-B accesses: half the registers of the x8 form -> twice the wavefronts in flight
+    static __device__ __forceinline__ void load(const __half *p, float (&v)[4])
+    {
+        const uint2 t = *reinterpret_cast<const uint2 *>(p);
+        const __half2 *h = reinterpret_cast<const __half2 *>(&t);
+        const float2 a = __half22float2(h[0]), b = __half22float2(h[1]);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    }
+    static __device__ __forceinline__ void store(__half *p, const float (&v)[4])
+    {
+        uint2 t;
+        __half2 *h = reinterpret_cast<__half2 *>(&t);
+        h[0] = __floats2half2_rn(v[0], v[1]);
+        h[1] = __floats2half2_rn(v[2], v[3]);
+        *reinterpret_cast<uint2 *>(p) = t;
+    }
+};
+template <>
 struct Seg<__half, 1> {
     static __device__ __forceinline__ void load(const __half *p, float (&v)[1]) { v[0] = __half2float(*p); }
     static __device__ __forceinline__ void store(__half *p, const float (&v)[1]) { *p = __float2half_rn(v[0]); }
@@ -443,9 +461,21 @@ int aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_
     __half *o = static_cast<__half *>(out);
     const bool vec = (F % 8 == 0) && (ldh % 8 == 0) && aligned16(Hd) && (!out || ((ldo % 8 == 0) && aligned16(out))) &&
                      side_aligned(bias, store_gate, pool_gate_a, pool_gate_b);
+#if defined(GGCN_HALF_VEC8)
     if (vec)
         return launch<__half, 8>(h, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
                                  pool_gate_b, o, ldo, pool_a, pool_b, st);
+#else
+    // 8-B accesses (4 halves per lane) measured faster than 16-B ones here: the x8 form needs
+    // 140 VGPRs (3 wavefronts per SIMD) and this kernel lives on latency hiding
+    const bool vec4 = (F % 4 == 0) && (ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(Hd) & 7u) == 0) &&
+                      (!out || ((ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 7u) == 0))) &&
+                      side_aligned(bias, store_gate, pool_gate_a, pool_gate_b);
+    (void)vec;
+    if (vec4)
+        return launch<__half, 4>(h, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
+                                 pool_gate_b, o, ldo, pool_a, pool_b, st);
+#endif
     return launch<__half, 1>(h, ldh, rowptr, colidx, vals, bias, B, T, F, store_gate, pool_gate_a,
                              pool_gate_b, o, ldo, pool_a, pool_b, st);
 }

@@ -155,3 +155,21 @@ def test_graph_batcher_matches_dense_slice():
     assert np.array_equal(mix.colidx.numpy(), ci2) and np.allclose(mix.vals.numpy(), v2)
     with pytest.raises(ValueError):
         bt.collate(["s0"], 40, "cpu")
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under ed-gated-gcn_amd/ (Python or HIP/C++) may
+    import, include, link or load it, and the C ABI takes no torch types."""
+    pkg_dir = os.path.join(ROOT, "ed-gated-gcn_amd")
+    bad = []
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"\boracle\b", text) or "ggcn_oracle" in text:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, "oracle referenced from the product tree: %s" % bad
+    header = open(os.path.join(ROOT, "include", "ggcn.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)          # prototypes without the comments
+    assert "torch" not in code.lower() and "tensor" not in code.lower()
+    assert 'extern "C"' in code
