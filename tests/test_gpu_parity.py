@@ -524,3 +524,27 @@ def test_config5_bert_base_end_to_end(pkg, dev):
     np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.numpy(), rtol=0, atol=1e-3)
     assert abs(float(xy) - float(ref_xy)) <= 1e-3 * abs(float(ref_xy))
     assert abs(float(kl) - float(ref_kl)) <= 1e-4
+
+
+def test_hipgraph_capture_replays_bit_identically(pkg, dev):
+    """include/ggcn.h promises enqueue-only entry points: the whole block captures into a hipGraph."""
+    from ed_gated_gcn_amd import synth
+    from ed_gated_gcn_amd.graphs import CapturedGatedBlock
+    B, T, H = 64, 31, 256
+    adj = synth.dependency_batch(B, T, 3.5, seed=4, lengths=np.random.default_rng(1).integers(5, T + 1, size=B))
+    rp, ci, _ = synth.csr_from_dense_host(adj)
+    csr = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, H, generator=gen).to(dev)
+    g1, g2 = torch.rand(B, H, generator=gen).to(dev), torch.rand(B, H, generator=gen).to(dev)
+    w1, b1 = synth.layer_params(H, H, seed=1)
+    w2, b2 = synth.layer_params(H, H, seed=2)
+    gc1, gc2 = _layer(pkg, dev, w1, b1, "bf16x3"), _layer(pkg, dev, w2, b2, "bf16x3")
+    cap = CapturedGatedBlock(x, csr, g1, g2, gc1, gc2)
+    x2 = torch.randn(B, T, H, generator=gen).to(dev)
+    with torch.no_grad():
+        ref = pkg.gated_gcn_block(x2, csr, g1, g2, gc1, gc2)
+    got = cap(x2, g1, g2)
+    torch.cuda.synchronize()
+    for k in ("gcn1", "x", "out", "x1", "y1", "xy"):
+        assert torch.equal(ref[k], got[k]), k
