@@ -39,14 +39,24 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 256, BK = 32;
+// GGCN_RN = 32-column MFMA tiles per wavefront: 2 (default: 4 wavefronts side by side, 128x64 each,
+// two workgroups per CU) or 4 (2 x 2 wavefronts, 128x128 each, 256 accumulator registers, ONE
+// workgroup per CU = one wavefront per SIMD with the whole 512-register file).
+#ifndef GGCN_RN
+#define GGCN_RN 2
+#endif
+constexpr int RN = GGCN_RN;
+constexpr int WN = 8 / RN;            // wavefronts along F
+constexpr int WM = 4 / WN;            // wavefronts along the rows
+constexpr int kWavesPerSimd = (RN == 2) ? 2 : 1;
+constexpr int BM = 128 * WM, BN = 256, BK = 32;
 constexpr int KSTEP = 16;             // K per MFMA
 constexpr int KS = BK / KSTEP;        // MFMA k-steps per stage
 constexpr int ROWB = BK * 2;          // bytes per LDS row of one plane (64)
 constexpr int NT = 32;                // columns per MFMA tile
 constexpr int FRAG_BYTES = 64 * 16;   // one B fragment: 64 lanes x 8 bf16
 constexpr int kThreads = 256;
-constexpr int kLdsBytes = 2 * 2 * BM * ROWB;  // [buffer][plane][128 rows x 64 B] = 32 KiB
+constexpr int kLdsBytes = 2 * 2 * BM * ROWB;  // [buffer][plane][BM rows x 64 B] = 32 KiB (64 KiB when BM = 256)
 
 // Staging geometry of one 128 x 32 stage of A for element type AT: every thread moves 16 B per
 // pass.  fp32: 8 threads per row, 32 rows per pass, 4 passes;  fp16: 4 per row, 64 rows, 2 passes.
@@ -136,7 +146,7 @@ __device__ __forceinline__ void load16(const AT *p, float (&v)[Geom<AT>::EPT])
 template <typename AT, bool AVEC, bool KFULL, bool ZROWS>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int k_steps,
-                                         int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][2])
+                                         int wm, int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN])
 {
     using G = Geom<AT>;
     constexpr int EPT = G::EPT, NP = G::NP;
@@ -223,23 +233,31 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 
     // B fragments straight from the packed image; indices clamped, never predicated: a column
     // tile past F duplicates the last real tile and is never stored.
-    const int ntc0 = nt0 < n_tiles_total ? nt0 : n_tiles_total - 1;
-    const int ntc1 = nt0 + 1 < n_tiles_total ? nt0 + 1 : n_tiles_total - 1;
-    const char *bbase0 = wpack + ((int64_t)ntc0 * k_steps) * 2 * FRAG_BYTES + lane * 16;
-    const char *bbase1 = wpack + ((int64_t)ntc1 * k_steps) * 2 * FRAG_BYTES + lane * 16;
-    auto load_b = [&](int ks, bf16x8 (&b)[2][2]) {  // [col tile][plane]
-        ks = ks < k_steps ? ks : k_steps - 1;       // the one-step-ahead prefetch of the last stage
+    const char *bbase[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int ntc = nt0 + j < n_tiles_total ? nt0 + j : n_tiles_total - 1;
+        bbase[j] = wpack + ((int64_t)ntc * k_steps) * 2 * FRAG_BYTES + lane * 16;
+    }
+    auto load_b = [&](int ks, bf16x8 (&b)[RN][2]) {  // [col tile][plane]
+        ks = ks < k_steps ? ks : k_steps - 1;        // the one-step-ahead prefetch of the last stage
         const int64_t o = (int64_t)ks * 2 * FRAG_BYTES;
-        b[0][0] = *reinterpret_cast<const bf16x8 *>(bbase0 + o);
-        b[0][1] = *reinterpret_cast<const bf16x8 *>(bbase0 + o + FRAG_BYTES);
-        b[1][0] = *reinterpret_cast<const bf16x8 *>(bbase1 + o);
-        b[1][1] = *reinterpret_cast<const bf16x8 *>(bbase1 + o + FRAG_BYTES);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            b[j][0] = *reinterpret_cast<const bf16x8 *>(bbase[j] + o);
+            b[j][1] = *reinterpret_cast<const bf16x8 *>(bbase[j] + o + FRAG_BYTES);
+        }
     };
 
-    const int f_row = lane & 31;
+    const int f_row = wm * 128 + (lane & 31);
     const int f_half = lane >> 5;
     // one 32-row block of one k-step: 2 LDS fragment reads + 6 MFMAs (3 products x 2 column tiles)
-    auto mma_block = [&](int buf, int s, int i, const bf16x8 (&b)[2][2]) {
+    auto mma_block = [&](int buf, int s, int i, const bf16x8 (&b)[RN][2]) {
+#if !defined(GGCN_LAB_NO_IGLP)
+        // LLVM's MFMA/DS interleave strategy for this scheduling region: measured -4 % on the fused
+        // layer (448 vs 467 us, same process, three orderings)
+        __builtin_amdgcn_iglp_opt(0);
+#endif
         const char *hi_plane = lds + buf * (2 * BM * ROWB);
         const char *lo_plane = hi_plane + BM * ROWB;
         const int off = a_lds_off(f_row + i * 32, s * 2 + f_half);
@@ -250,7 +268,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         // clock the chip holds on that shape (MI355X_MICROARCH.md DVFS item 7)
         typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < RN; ++j) {
             f32x4 q[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) q[t] = f32x4{acc[i][j][4 * t], acc[i][j][4 * t + 1], acc[i][j][4 * t + 2], acc[i][j][4 * t + 3]};
@@ -267,7 +285,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         }
 #else
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < RN; ++j) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][1], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][0], acc[i][j], 0, 0, 0);
@@ -278,12 +296,12 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < RN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    static_assert(BK == 32 && NP <= 4, "the interleaved stage below is written for BK = 32");
-    bf16x8 b0[2][2], b1[2][2];
+    static_assert(BK == 32 && NP <= 8, "the interleaved stage below is written for BK = 32");
+    bf16x8 b0[RN][2], b1[RN][2];
     const int stages = (K + BK - 1) / BK;
     const int last_k0 = (stages - 1) * BK;
 
@@ -315,10 +333,18 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
                 store_a_pass(buf ^ 1, i, k_next1);  // rows of stage st+1 -> the other buffer
                 load_a_pass(i, ka);         // rows of stage st+2
             }
+            if (i + 4 < NP) {
+                store_a_pass(buf ^ 1, i + 4, k_next1);
+                load_a_pass(i + 4, ka);
+            }
+#if !defined(GGCN_LAB_NO_SB)
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         load_b(st * KS + 2, b0);
+#if !defined(GGCN_LAB_NO_SB2)
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) mma_block(buf, 1, i, b1);
         __syncthreads();  // the only barrier of the stage

@@ -44,7 +44,7 @@ __device__ __forceinline__ void split2(const f32x16 &acc, bf16x8 (&frag)[2][2])
 
 // FULLT: T == 32 and B % 4 == 0 (every row of every tile is a real node): drops every guard.
 template <bool AVEC, bool KFULL, bool FULLT>
-__global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
     const float *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
     const uint32_t *__restrict__ rowmask, const float *__restrict__ bias, int B, int T, int K, int F,
     const float *__restrict__ store_gate, const float *__restrict__ pool_gate_a,
@@ -70,10 +70,12 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g0 = g_tile * 4;  // 4 graph slots of 32 rows per workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int gt0 = g_tile * (4 * WM);  // graph slots of 32 rows in this workgroup's tile
+    const int g0 = gt0 + wm * 4;        // this wavefront's 4 graphs
     const int n_tiles_total = (F + NT - 1) / NT;
-    const int nt0 = n_wgi * (BN / NT) + wn * 2;
+    const int nt0 = n_wgi * (BN / NT) + wn * RN;
 
     // tile row 32*slot + r  <->  node r of graph g0+slot
     constexpr int NP = Geom<float>::NP;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int row = stage_row<float>(i);
-        const int g = g0 + (row >> 5), r = row & 31;
+        const int g = gt0 + (row >> 5), r = row & 31;
         avalid[i] = (g < B) && (FULLT || r < T);
         const int64_t node = avalid[i] ? (int64_t)g * T + r : 0;  // clamped, zeroed by the select
         arow[i] = X + node * ldx;
@@ -97,16 +99,16 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
         mask[i] = ok ? m : 0u;
     }
 
-    f32x16 acc[4][2];
-    mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);
+    f32x16 acc[4][RN];
+    mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, k_steps, wm, nt0, n_tiles_total, lds, acc);
 
     const int c = lane & 31, h = lane >> 5;
 
     // bias and the gates of the 4 graphs x 2 column tiles: all loads issued together, one latency
-    float vb[2], vsg[4][2], vga[4][2], vgb[4][2];
-    bool col_ok[2];
+    float vb[RN], vsg[4][RN], vga[4][RN], vgb[4][RN];
+    bool col_ok[RN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < RN; ++j) {
         const int gn = (nt0 + j) * NT + c;
         col_ok[j] = gn < F;
         const int gnc = col_ok[j] ? gn : 0;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kThreads, 2) void layer_fused_kernel(
         }
 
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < RN; ++j) {
             if (nt0 + j >= n_tiles_total) break;  // wavefront-uniform: column tile past F
             const int gn = (nt0 + j) * NT + c;
 
@@ -233,12 +235,12 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
     const bool avec = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
     const bool kfull = (K % BK == 0);
     const int k_steps = round_up(K, BK) / KSTEP;
-    const int64_t g_tiles = ((int64_t)B + 3) / 4;
+    const int64_t g_tiles = ((int64_t)B + 4 * WM - 1) / (4 * WM);
     const int n_wg = (F + BN - 1) / BN;
     const int64_t grid = grid_for(g_tiles, n_wg);
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: batch too large");
     const char *wp = static_cast<const char *>(wpack);
-    const bool fullt = (T == 32) && (B % 4 == 0);
+    const bool fullt = (T == 32) && (B % (4 * WM) == 0);
 #define GGCN_LAUNCH(AV, KF, FT)                                                                                  \
     hipLaunchKernelGGL((layer_fused_kernel<AV, KF, FT>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
                        rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, (int)ldo, pool_a,    \

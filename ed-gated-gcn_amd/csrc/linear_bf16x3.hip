@@ -49,7 +49,7 @@ __device__ __forceinline__ void store_elem(__half *p, float v) { *p = __float2ha
 
 // ET: element type of X and Y (float, or __half with fp32 accumulation)
 template <typename ET, bool AVEC, bool KFULL>
-__global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_bf16x3_kernel(
     const ET *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
     ET *__restrict__ Y, int64_t ldy, int64_t M, int K, int F, int m_tiles, int n_wg, int k_steps)
 {
@@ -59,10 +59,11 @@ __global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wn = tid >> 6;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
     const int64_t m0 = (int64_t)m_tile * BM;
     const int n_tiles_total = (F + NT - 1) / NT;
-    const int nt0 = n_wgi * (BN / NT) + wn * 2;  // this wavefront's first 32-column tile
+    const int nt0 = n_wgi * (BN / NT) + wn * RN;  // this wavefront's first 32-column tile
 
     // rows past M are clamped to row M-1: a row of A only feeds the same row of Y, never stored
     constexpr int NP = Geom<ET>::NP;
@@ -75,18 +76,18 @@ __global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
         arow[i] = X + gm * ldx;
         avalid[i] = true;
     }
-    f32x16 acc[4][2];
-    mainloop<ET, AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps, nt0, n_tiles_total, lds, acc);
+    f32x16 acc[4][RN];
+    mainloop<ET, AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps, wm, nt0, n_tiles_total, lds, acc);
 
 #ifndef GGCN_LAB_NO_STORE
     const bool full_rows = m0 + BM <= M;  // workgroup-uniform: the row guard only exists in the last tile
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < RN; ++j) {
         const int gn = (nt0 + j) * NT + (lane & 31);
         if (gn >= F) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int64_t gmb = m0 + i * 32 + 4 * (lane >> 5);
+            const int64_t gmb = m0 + wm * 128 + i * 32 + 4 * (lane >> 5);
             ET *yb = Y + gmb * ldy + gn;
             if (full_rows) {
 #pragma unroll
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(kThreads, 2) void linear_bf16x3_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        for (int j = 0; j < RN; ++j) asm volatile("" ::"v"(acc[i][j]));
     if (M < 0) store_elem(Y, 0.f);
 #endif
 }
