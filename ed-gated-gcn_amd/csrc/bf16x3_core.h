@@ -345,8 +345,14 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 #if !defined(GGCN_LAB_NO_SB2)
         __builtin_amdgcn_sched_barrier(0);
 #endif
+#if defined(GGCN_LAB_PRIO)
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) mma_block(buf, 1, i, b1);
+#if defined(GGCN_LAB_PRIO)
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();  // the only barrier of the stage
     };
     int st = 0;

@@ -133,6 +133,10 @@ class GraphConvolution(nn.Module):
         self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "bf16x3")
         # one-launch layer (fused_layer.hip) when the batch allows it: T <= 32, binary adjacency, bf16x3
         self.fused = bool(getattr(opt, "ggcn_fused", True)) and os.environ.get("GGCN_FUSED", "1") != "0"
+        # dense adjacency handed to forward(): None = let the device detect edge weights (one 4-byte
+        # read-back per conversion), True = promise 0/1 entries like the reference's (graph.py:66-74)
+        # and stay sync-free, False = always keep the values
+        self.binary_adj = getattr(opt, "ggcn_binary_adj", None)
         self._pack = None
         self._pack_key = None
 
@@ -173,7 +177,7 @@ class GraphConvolution(nn.Module):
             raise RuntimeError("adj %s does not match text %s" % (tuple(adj.shape), tuple(text.shape)))
         if adj.device != text.device:
             raise RuntimeError("adj and text are on different devices")
-        return BatchedCSR.from_dense(adj)  # gcn.py:33 accepts any real dtype
+        return BatchedCSR.from_dense(adj, binary=self.binary_adj)  # gcn.py:33 accepts any real dtype
 
     def _check(self, text):
         # float16 features (BASELINE configs[3]) are an extension: the reference itself raises a
