@@ -273,7 +273,7 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline and world >= 1:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only: other ranks would idle at the barrier
             t = torch.from_numpy
             result["cpu_baseline"] = cpu_baseline(x_cpu, t(adj_np), g1_cpu, g2_cpu, t(w1), t(b1), t(w2), t(b2),
                                                   args.cpu_graphs)
