@@ -23,9 +23,9 @@ PROTOTYPES = {
     "ggcn_rowmask_from_dense": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "ggcn_csr_rowmask": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_layer_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
-                                 c_vp, c_i64, c_vp, c_vp, c_vp]),
-    "ggcn_weight_pack_bytes": (c_sz, [c_i32, c_i32]),
-    "ggcn_weight_pack": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+                                 c_vp, c_i64, c_vp, c_vp, c_i32, c_vp]),
+    "ggcn_weight_pack_bytes": (c_sz, [c_i32, c_i32, c_i32]),
+    "ggcn_weight_pack": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_linear": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -33,18 +33,18 @@ PROTOTYPES = {
                                         c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "ggcn_dweight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
     "ggcn_dweight": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
-    "ggcn_weight_pack_t": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_inv_denominators": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "ggcn_aggregate_t": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
-    "ggcn_linear_h": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    "ggcn_linear_h": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_aggregate_h": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                  c_vp, c_i64, c_vp, c_vp, c_vp]),
     "ggcn_overlap_workspace_bytes": (c_sz, [c_i32]),
     "ggcn_gate_overlap": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 
-ABI_VERSION = 1
-PREC = {"bf16x3": 0, "fp32": 1}
+ABI_VERSION = 2
+PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2}
+PACKED = ("bf16x3", "f16mx8")  # precisions whose linear reads a ggcn_weight_pack image
 FLAG_WEIGHTED = 1
 
 

@@ -58,22 +58,18 @@ int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
 int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask,
                      const float *bias, int B, int T, int K, int F, const float *store_gate,
                      const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
-                     float *pool_a, float *pool_b, ggcn_stream_t stream)
+                     float *pool_a, float *pool_b, int precision, ggcn_stream_t stream)
 {
     return layer_fused(X, ldx, wpack, rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out,
-                       ldo, pool_a, pool_b, as_stream(stream));
+                       ldo, pool_a, pool_b, precision, as_stream(stream));
 }
 
-size_t ggcn_weight_pack_bytes(int K, int F) { return weight_pack_bytes(K, F); }
+size_t ggcn_weight_pack_bytes(int K, int F, int precision) { return weight_pack_bytes(K, F, precision); }
 
-int ggcn_weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, ggcn_stream_t stream)
+int ggcn_weight_pack(const float *W, int64_t ldw, int K, int F, int precision, int transposed, void *wpack,
+                     ggcn_stream_t stream)
 {
-    return weight_pack(W, ldw, K, F, wpack, false, as_stream(stream));
-}
-
-int ggcn_weight_pack_t(const float *W, int64_t ldw, int K, int F, void *wpack, ggcn_stream_t stream)
-{
-    return weight_pack(W, ldw, K, F, wpack, true, as_stream(stream));
+    return weight_pack(W, ldw, K, F, precision, transposed != 0, wpack, as_stream(stream));
 }
 
 int ggcn_aggregate_t(const float *G, int64_t ldg, const int32_t *rowptr_t, const int32_t *colidx_t,
@@ -98,7 +94,8 @@ int ggcn_linear(const float *X, int64_t ldx, const float *W, int64_t ldw, const 
     if (ldx < K || ldy < F) return fail(GGCN_EINVAL, "ggcn_linear: leading dimension too small");
     switch (precision) {
         case GGCN_PREC_BF16X3:
-            return linear_bf16x3(X, ldx, wpack, Y, ldy, M, K, F, as_stream(stream));
+        case GGCN_PREC_F16MX8:
+            return linear_packed(X, ldx, wpack, Y, ldy, M, K, F, precision, as_stream(stream));
         case GGCN_PREC_FP32:
             if (!W) return fail(GGCN_EINVAL, "ggcn_linear(fp32): W is NULL");
             if (ldw < F) return fail(GGCN_EINVAL, "ggcn_linear(fp32): ldw < F");
@@ -118,13 +115,15 @@ int ggcn_aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const in
 }
 
 int ggcn_linear_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M, int K, int F,
-                  ggcn_stream_t stream)
+                  int precision, ggcn_stream_t stream)
 {
+    if (precision != GGCN_PREC_BF16X3 && precision != GGCN_PREC_F16MX8)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_linear_h: precision %d (use bf16x3 or f16mx8)", precision);
     if (!X || !Y) return fail(GGCN_EINVAL, "ggcn_linear_h: null pointer");
     if (M <= 0 || K <= 0 || F <= 0)
         return fail(GGCN_EINVAL, "ggcn_linear_h: M=%lld K=%d F=%d must be positive", (long long)M, K, F);
     if (ldx < K || ldy < F) return fail(GGCN_EINVAL, "ggcn_linear_h: leading dimension too small");
-    return linear_bf16x3_h(X, ldx, wpack, Y, ldy, M, K, F, as_stream(stream));
+    return linear_packed_h(X, ldx, wpack, Y, ldy, M, K, F, precision, as_stream(stream));
 }
 
 int ggcn_aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,

@@ -37,13 +37,13 @@ int rowmask_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb,
 int linear_fp32(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y, int64_t ldy,
                 int64_t M, int K, int F, hipStream_t st);
 
-size_t weight_pack_bytes(int K, int F);
-int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, bool transposed, hipStream_t st);
-int linear_bf16x3(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy,
-                  int64_t M, int K, int F, hipStream_t st);
+size_t weight_pack_bytes(int K, int F, int precision);
+int weight_pack(const float *W, int64_t ldw, int K, int F, int precision, bool transposed, void *wpack, hipStream_t st);
+int linear_packed(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy,
+                  int64_t M, int K, int F, int precision, hipStream_t st);
 
-int linear_bf16x3_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M, int K,
-                    int F, hipStream_t st);
+int linear_packed_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M, int K,
+                    int F, int precision, hipStream_t st);
 int aggregate_t(const float *G, int64_t ldg, const int32_t *rowptr_t, const int32_t *colidx_t,
                 const float *vals_t, const float *src_scale, int B, int T, int F, float *out, int64_t ldo,
                 hipStream_t st);
@@ -60,7 +60,8 @@ int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t
 int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask, hipStream_t st);
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const float *bias,
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
-                const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b, hipStream_t st);
+                const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b, int precision,
+                hipStream_t st);
 
 int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                        const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,

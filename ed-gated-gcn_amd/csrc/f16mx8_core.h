@@ -1,0 +1,284 @@
+// Main loop of the "f16mx8" linear: fp32-accurate X.W with TWO MFMA units per product instead
+// of the three of bf16x3 (bf16x3_core.h), same tiling, same LDS footprint.
+//
+//   x = xh + xl,  xh = fp16(x) (11 bits, RNE),  xl = x - xh  (exact in fp32, |xl| <= 2^-11 |x|)
+//   w = wh + wl   likewise (made once by ggcn_weight_pack)
+//   x.w = xh.wh + (xl.wh + xh.wl) + xl.wl
+//         `--- v_mfma_f32_32x32x16_f16, exact products, fp32 accumulate
+//                  `--- ONE block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3):
+//                       its 64-deep K is [block 0 | block 1] = [xl.wh | xh.wl] over the SAME 32 k,
+//                       each block with its own power-of-two scale (MX); it runs at twice the bf16
+//                       rate, so it costs what ONE bf16 MFMA pair costs
+//                               `--- dropped: <= 2^-22 |x.w|
+// The correction is ~2^-12 of the product, so fp8's 2^-4 relative precision leaves ~2^-16 -- the
+// same order as bf16x3 -- for 2/3 of the matrix-pipe time (128 instead of 192 cycles per 32 k of a
+// 32x32 tile).
+//
+// MX operand facts measured with tools/probes/mx_fp8_probe.py (exact-integer data, gfx950):
+//   * A (and B) operand: lane l = (r = l&31, h = l>>5) holds 32 bytes; byte j is
+//     k = 32*(j>>4) + 16*h + (j&15): bytes 0-15 belong to scale block 0, bytes 16-31 to block 1;
+//   * the E8M0 scale of (row r, block b) is byte 0 (opsel 0) of the scale VGPR of lane r + 32*b;
+//     value = stored * 2^(scale - 127).
+// A-side scales are FIXED: xl is stored as xl*2^11 (scale byte 116), xh as it is (127).  fp8 e4m3
+// then covers |x| in [2^-9, 448]; below, the (already ~2^-12-small) correction flushes gradually;
+// above, it saturates and the result degrades gracefully to the fp16 product's 2^-12.  fp16 itself
+// needs |x| < 65504: this mode is for activations of ordinary magnitude (LSTM / GCN outputs);
+// bf16x3 keeps the full fp32 range.
+//
+// LDS per stage and buffer: plane 0 = xh as fp16 [128 rows][64 B], plane 1 = [xl8 (32 B) | xh8 (32 B)]
+// per row -- 128 B per row like bf16x3, same XOR chunk swizzle, same conflict-free reads.
+// Packed weight per (32-column tile, 32-deep stage): [f16 frag k-step 0: 1 KiB][k-step 1: 1 KiB]
+// [MX operand: 64 lanes x 32 B][scales: 64 lanes x 4 B] = 4352 B.
+#pragma once
+#include "bf16x3_core.h"
+
+namespace ggcn {
+namespace mx8 {
+
+using namespace bx3;  // geometry, LDS addressing, tile mapping are shared
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int STAGE_PACK_BYTES = 2 * 1024 + 64 * 32 + 64 * 4;  // 4352
+constexpr int XL_SHIFT = 11;                                    // xl is stored as xl * 2^11
+constexpr int SCALE_XL = 127 - XL_SHIFT, SCALE_XH = 127;
+
+// ---- the split of 4 consecutive fp32 values: 10 VALU instructions -----------------------------
+//   2 x v_cvt_pk_f16_f32 (RNE)            xh as two fp16 pairs
+//   4 x v_fma_mix_f32  x - float(xh)      the residual, exact (fp16 factor read straight from the pair)
+//   2 x v_cvt_scalef32_pk_fp8_f32         fp8(xl / 2^-11): the scale operand DIVIDES (cvt_probe.py)
+//   2 x v_cvt_pk_fp8_f32 of x itself      fp8(x) stands in for fp8(xh): it only feeds the correction
+struct Split4 {
+    uint32_t h01, h23;  // fp16 pairs
+    int l8, h8;         // 4 x fp8 of xl * 2^11, 4 x fp8 of x
+};
+__device__ __forceinline__ Split4 split4(float x0, float x1, float x2, float x3)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const h2 p0 = __builtin_convertvector(f2{x0, x1}, h2);
+    const h2 p1 = __builtin_convertvector(f2{x2, x3}, h2);
+    float r0, r1, r2, r3;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(p0), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(p0), "v"(x1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(p1), "v"(x2));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(p1), "v"(x3));
+    constexpr float inv = 1.0f / (float)(1 << XL_SHIFT);
+    s2 q = {0, 0};
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, r0, r1, inv, false);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, r2, r3, inv, true);
+    int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, 0, false);
+    h8 = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, h8, true);
+    Split4 o;
+    o.h01 = __builtin_bit_cast(uint32_t, p0);
+    o.h23 = __builtin_bit_cast(uint32_t, p1);
+    o.l8 = __builtin_bit_cast(int, q);
+    o.h8 = h8;
+    return o;
+}
+
+// MODE.FP16_OVFL (hwreg MODE bit 23): overflowing fp16 and fp8 conversions clamp to the largest finite
+// value instead of producing inf / NaN (checked by tools/probes/cvt_probe.py), so |x| > 448 only
+// costs the correction its accuracy and |x| > 65504 saturates like any fp16 pipeline.
+__device__ __forceinline__ void set_cvt_saturate(bool on) { __builtin_amdgcn_s_setreg(1 | (23 << 6), on ? 1 : 0); }
+
+#define GGCN_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <typename AT, bool AVEC, bool KFULL, bool ZROWS>
+__device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
+                                         const char *__restrict__ wpack, int K, int stages_packed, int wm,
+                                         int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN])
+{
+    using G = Geom<AT>;
+    constexpr int EPT = G::EPT, NP = G::NP, NQ = EPT / 4;
+    static_assert(BK == 32 && NP <= 4 && RN == 2, "the slot schedule below is written for BK = 32, <= 4 passes, RN = 2");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int s_k = (tid % G::TPR) * EPT;
+
+    set_cvt_saturate(true);
+
+    float ra[NP][EPT];
+    auto load_a_pass = [&](int i, int k0) {
+        const int gk = k0 + s_k;
+        if constexpr (AVEC) {
+            load16<AT>(arow[i] + ((KFULL || gk < K) ? gk : 0), ra[i]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < EPT; ++c) ra[i][c] = elem_to_float(arow[i][(gk + c < K) ? gk + c : 0]);
+        }
+    };
+    // pass i of the stage that starts at k0: registers -> split -> LDS buffer `buf`
+    // (plane 0: fp16 xh; plane 1: [xl8 k 0-15 | xl8 k 16-31 | xh8 k 0-15 | xh8 k 16-31])
+    Split4 sp[NQ];
+    auto split_pass = [&](int i, int k0) {
+        const int gk = k0 + s_k;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float x[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                x[c] = ra[i][4 * q + c];
+                if constexpr (!KFULL || ZROWS) {
+                    bool in = true;
+                    if constexpr (!KFULL) in = gk + 4 * q + c < K;
+                    if constexpr (ZROWS) in = in && avalid[i];
+                    x[c] = in ? x[c] : 0.0f;
+                }
+            }
+            sp[q] = split4(x[0], x[1], x[2], x[3]);
+        }
+    };
+    auto write_pass = [&](int buf, int i) {
+        char *h_plane = lds + buf * (2 * BM * ROWB);
+        char *q_plane = h_plane + BM * ROWB;
+        const int row = stage_row<AT>(i);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int kq = s_k + 4 * q;  // k offset inside the 32-deep stage
+            *reinterpret_cast<uint2 *>(h_plane + a_lds_off(row, kq >> 3) + (kq & 4) * 2) = make_uint2(sp[q].h01, sp[q].h23);
+            *reinterpret_cast<int *>(q_plane + a_lds_off(row, kq >> 4) + (kq & 15)) = sp[q].l8;
+            *reinterpret_cast<int *>(q_plane + a_lds_off(row, 2 + (kq >> 4)) + (kq & 15)) = sp[q].h8;
+        }
+    };
+
+    // packed B: per stage [f16 k-step 0][f16 k-step 1][mx][scales]
+    const char *bbase[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int ntc = nt0 + j < n_tiles_total ? nt0 + j : n_tiles_total - 1;
+        bbase[j] = wpack + (int64_t)ntc * stages_packed * STAGE_PACK_BYTES + lane * 16;
+    }
+    auto load_bf = [&](int st, f16x8 (&b0)[RN], f16x8 (&b1)[RN]) {  // fp16 fragments of both k-steps of stage st
+        st = st < stages_packed ? st : stages_packed - 1;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES;
+            b0[j] = *reinterpret_cast<const f16x8 *>(p);
+            b1[j] = *reinterpret_cast<const f16x8 *>(p + 1024);
+        }
+    };
+    auto load_bq = [&](int st, i32x8 (&b)[RN], int (&sc)[RN]) {  // MX operand + scales of stage st
+        st = st < stages_packed ? st : stages_packed - 1;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES + 2048 + lane * 16;  // lane * 32 in all
+            const i32x4 lo = *reinterpret_cast<const i32x4 *>(p);
+            const i32x4 hi = *reinterpret_cast<const i32x4 *>(p + 16);
+            b[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            sc[j] = *reinterpret_cast<const int *>(bbase[j] + (int64_t)st * STAGE_PACK_BYTES + 4096 - lane * 12);
+        }
+    };
+
+    const int f_row = wm * 128 + (lane & 31);
+    const int f_half = lane >> 5;
+    const int scale_a = f_half ? SCALE_XH : SCALE_XL;  // lane r+32b carries the scale of block b
+    auto read_h = [&](int buf, int i, f16x8 (&a)[2]) {
+        const char *h_plane = lds + buf * (2 * BM * ROWB);
+        const int row = f_row + i * 32;
+        a[0] = *reinterpret_cast<const f16x8 *>(h_plane + a_lds_off(row, f_half));
+        a[1] = *reinterpret_cast<const f16x8 *>(h_plane + a_lds_off(row, 2 + f_half));
+    };
+    auto read_q = [&](int buf, int i, i32x8 &a) {
+        const char *q_plane = lds + buf * (2 * BM * ROWB) + BM * ROWB;
+        const int row = f_row + i * 32;
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, f_half));      // xl8, k = 16h..
+        const i32x4 hi = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, 2 + f_half));  // xh8, k = 16h..
+        a = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f16x8 b0[RN], b1[RN];
+    i32x8 bq[RN];
+    int sq[RN];
+#ifdef GGCN_MX_LAB_KDIV  // timing probe: 1/KDIV of the main loop, same prologue and epilogue
+    const int stages = (K + BK - 1) / BK / GGCN_MX_LAB_KDIV;
+#else
+    const int stages = (K + BK - 1) / BK;
+#endif
+    const int last_k0 = (stages - 1) * BK;
+
+#pragma unroll
+    for (int p = 0; p < NP; ++p) load_a_pass(p, 0);
+    load_bf(0, b0, b1);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        split_pass(p, 0);
+        write_pass(0, p);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) load_a_pass(p, BK < last_k0 ? BK : last_k0);
+    __syncthreads();
+
+    // One stage = 8 slots of 128 matrix-pipe cycles each; the source order below IS the issue order
+    // (a sched_barrier after every group), so every MFMA has a few independent VALU / LDS / memory
+    // instructions behind it to issue in its shadow:
+    //   slots 0-3 (block i): 4 fp16 MFMAs  | split + LDS write of pass i of the NEXT stage, the
+    //                                        global load of pass i two stages ahead, the LDS reads
+    //                                        of the next block's fragments (one slot ahead of use)
+    //   slots 4-7 (block i): 2 MX  MFMAs   | the fp16 B fragments of the next stage, LDS reads
+    // The MX operand of B is loaded at the top of its stage (used from slot 4 on).
+    auto stage = [&](int st, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        const int k_next1 = (st + 1) * BK < last_k0 ? (st + 1) * BK : last_k0;
+        const int k_next2 = (st + 2) * BK;
+        const int ka = k_next2 < last_k0 ? k_next2 : last_k0;
+        f16x8 ah[2][2];
+        i32x8 aq[2];
+        read_h(buf, 0, ah[0]);
+        load_bq(st, bq, sq);
+        GGCN_SB();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < 3) read_h(buf, i + 1, ah[(i + 1) & 1]);
+            else read_q(buf, 0, aq[0]);
+            GGCN_SB();
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[0], acc[i][0], 0, 0, 0);
+            GGCN_SB();
+            if (i < NP) split_pass(i, k_next1);
+            GGCN_SB();
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[1], acc[i][1], 0, 0, 0);
+            GGCN_SB();
+            if (i < NP) write_pass(buf ^ 1, i);
+            GGCN_SB();
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[0], acc[i][0], 0, 0, 0);
+            GGCN_SB();
+            if (i < NP) load_a_pass(i, ka);
+            GGCN_SB();
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[1], acc[i][1], 0, 0, 0);
+            GGCN_SB();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < 3) read_q(buf, i + 1, aq[(i + 1) & 1]);
+            GGCN_SB();
+            acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bq[0], acc[i][0], 0, 0, 0, scale_a, 0, sq[0]);
+            GGCN_SB();
+            if (i == 0) load_bf(st + 1, b0, b1);  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
+            GGCN_SB();
+            acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bq[1], acc[i][1], 0, 0, 0, scale_a, 0, sq[1]);
+            GGCN_SB();
+        }
+        __syncthreads();
+    };
+    int st = 0;
+    for (; st + 1 < stages; st += 2) {
+        stage(st, std::integral_constant<int, 0>{});
+        stage(st + 1, std::integral_constant<int, 1>{});
+    }
+    if (st < stages) stage(st, std::integral_constant<int, 0>{});
+    set_cvt_saturate(false);
+}
+#undef GGCN_SB
+
+}  // namespace mx8
+}  // namespace ggcn

@@ -21,7 +21,7 @@
 // HBM traffic per layer = X in + out + 4 B/node masks + gates + W: the algorithmic bytes.
 // Graphs with T < 32 occupy a 32-row slot (rows >= T read as zeros, are never stored and never
 // pooled); T > 32 or weighted adjacency -> the unfused path (linear + aggregate.hip).
-#include "bf16x3_core.h"
+#include "f16mx8_core.h"
 
 namespace ggcn {
 namespace {
@@ -43,7 +43,8 @@ __device__ __forceinline__ void split2(const f32x16 &acc, bf16x8 (&frag)[2][2])
 }
 
 // FULLT: T == 32 and B % 4 == 0 (every row of every tile is a real node): drops every guard.
-template <bool AVEC, bool KFULL, bool FULLT>
+// SCH: 0 = bf16x3 main loop, 1 = f16mx8 (f16mx8_core.h)
+template <int SCH, bool AVEC, bool KFULL, bool FULLT>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
     const float *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
     const uint32_t *__restrict__ rowmask, const float *__restrict__ bias, int B, int T, int K, int F,
@@ -100,7 +101,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
     }
 
     f32x16 acc[4][RN];
-    mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, k_steps, wm, nt0, n_tiles_total, lds, acc);
+    if constexpr (SCH == 0)
+        bx3::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, k_steps, wm, nt0, n_tiles_total, lds, acc);
+    else
+        mx8::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
 
     const int c = lane & 31, h = lane >> 5;
 
@@ -221,8 +225,11 @@ int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint
 
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const float *bias,
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
-                const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b, hipStream_t st)
+                const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b, int precision,
+                hipStream_t st)
 {
+    if (precision != GGCN_PREC_BF16X3 && precision != GGCN_PREC_F16MX8)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: precision %d (use bf16x3 or f16mx8)", precision);
     if (!X || !wpack || !rowmask) return fail(GGCN_EINVAL, "ggcn_layer_fused: null input pointer");
     if (B <= 0 || T <= 0 || K <= 0 || F <= 0)
         return fail(GGCN_EINVAL, "ggcn_layer_fused: B=%d T=%d K=%d F=%d must be positive", B, T, K, F);
@@ -241,14 +248,20 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: batch too large");
     const char *wp = static_cast<const char *>(wpack);
     const bool fullt = (T == 32) && (B % (4 * WM) == 0);
-#define GGCN_LAUNCH(AV, KF, FT)                                                                                  \
-    hipLaunchKernelGGL((layer_fused_kernel<AV, KF, FT>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
-                       rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, (int)ldo, pool_a,    \
+#define GGCN_LAUNCH(SC, AV, KF, FT)                                                                                  \
+    hipLaunchKernelGGL((layer_fused_kernel<SC, AV, KF, FT>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
+                       rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, (int)ldo, pool_a,        \
                        pool_b, (int)g_tiles, n_wg, k_steps)
-    if (avec && kfull && fullt) GGCN_LAUNCH(true, true, true);
-    else if (avec && kfull) GGCN_LAUNCH(true, true, false);
-    else if (avec) GGCN_LAUNCH(true, false, false);
-    else GGCN_LAUNCH(false, false, false);
+#define GGCN_PICK(SC)                                            \
+    do {                                                         \
+        if (avec && kfull && fullt) GGCN_LAUNCH(SC, true, true, true);   \
+        else if (avec && kfull) GGCN_LAUNCH(SC, true, true, false);      \
+        else if (avec) GGCN_LAUNCH(SC, true, false, false);              \
+        else GGCN_LAUNCH(SC, false, false, false);                       \
+    } while (0)
+    if (precision == GGCN_PREC_F16MX8) GGCN_PICK(1);
+    else GGCN_PICK(0);
+#undef GGCN_PICK
 #undef GGCN_LAUNCH
     return check_launch("ggcn_layer_fused");
 }

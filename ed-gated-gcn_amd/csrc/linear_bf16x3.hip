@@ -13,7 +13,7 @@
 // Kernel shape, operand lane maps and the measured scheduling notes: bf16x3_core.h (the main
 // loop is shared with fused_layer.hip).  This file adds the weight packer and the plain-store
 // epilogue.
-#include "bf16x3_core.h"
+#include "f16mx8_core.h"
 
 namespace ggcn {
 namespace {
@@ -44,11 +44,71 @@ __global__ __launch_bounds__(128) void weight_pack_kernel(const float *__restric
     pack[(((int64_t)n_tile * k_steps + k_step) * 2 + plane) * 64 + lane] = v;
 }
 
+// ---- W -> f16mx8 image: per (32-column tile, 32-deep stage) [f16 frag k-step 0][k-step 1]
+// [MX operand 64 x 32 B][scales 64 x 4 B]; see f16mx8_core.h.  block = 64 threads = one wavefront.
+template <bool TR>
+__global__ __launch_bounds__(64) void weight_pack_mx8_kernel(const float *__restrict__ W, int64_t ldw, int K, int F,
+                                                            int stages, char *__restrict__ pack)
+{
+    const int n_tile = blockIdx.x, st = blockIdx.y, lane = threadIdx.x;
+    const int c = lane & 31, h = lane >> 5;
+    const int n = n_tile * NT + c;
+    char *base = pack + ((int64_t)n_tile * stages + st) * mx8::STAGE_PACK_BYTES;
+    auto wat = [&](int k) -> float {
+        return (k < K && n < F) ? (TR ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n]) : 0.0f;
+    };
+    // fp16 fragments: k-step s, lane (c, h): k = 32 st + 16 s + 8 h + j
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        mx8::f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)wat(32 * st + 16 * s2 + 8 * h + j);
+        *reinterpret_cast<mx8::f16x8 *>(base + s2 * 1024 + lane * 16) = v;
+    }
+    // MX operand: lane (c, h): bytes 0-15 = block 0 = fp8(wh * 2^s0), bytes 16-31 = block 1 = fp8(wl * 2^s1),
+    // both for k = 32 st + 16 h + jj; one power-of-two scale per (column, block) over the 32 k of the stage
+    float wh[16], wl[16], m0 = 0.0f, m1 = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const float w = wat(32 * st + 16 * h + jj);
+        wh[jj] = (float)(_Float16)w;
+        wl[jj] = w - wh[jj];
+        m0 = fmaxf(m0, fabsf(wh[jj]));
+        m1 = fmaxf(m1, fabsf(wl[jj]));
+    }
+    m0 = fmaxf(m0, __shfl_xor(m0, 32));
+    m1 = fmaxf(m1, __shfl_xor(m1, 32));
+    auto shift_for = [](float m) -> int {  // largest s with m * 2^s < 2^8 (e4m3 max is 448)
+        if (!(m > 0.0f)) return 0;
+        int e;
+        (void)frexpf(m, &e);               // m = f * 2^e, f in [0.5, 1)
+        int s = 8 - e;
+        return s > 100 ? 100 : (s < -100 ? -100 : s);
+    };
+    const int s0 = shift_for(m0), s1 = shift_for(m1);
+    int q[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int a = 0, b = 0;
+        a = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wh[4 * t], s0), ldexpf(wh[4 * t + 1], s0), a, false);
+        a = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wh[4 * t + 2], s0), ldexpf(wh[4 * t + 3], s0), a, true);
+        b = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wl[4 * t], s1), ldexpf(wl[4 * t + 1], s1), b, false);
+        b = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wl[4 * t + 2], s1), ldexpf(wl[4 * t + 3], s1), b, true);
+        q[t] = a;
+        q[4 + t] = b;
+    }
+    int *mxp = reinterpret_cast<int *>(base + 2048 + lane * 32);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) mxp[t] = q[t];
+    // lane c carries the scale of block 0, lane c + 32 the scale of block 1 (E8M0: value = 2^(byte-127))
+    *reinterpret_cast<int *>(base + 4096 + lane * 4) = 127 - (h ? s1 : s0);
+}
+
 __device__ __forceinline__ void store_elem(float *p, float v) { *p = v; }
 __device__ __forceinline__ void store_elem(__half *p, float v) { *p = __float2half_rn(v); }
 
-// ET: element type of X and Y (float, or __half with fp32 accumulation)
-template <typename ET, bool AVEC, bool KFULL>
+// ET: element type of X and Y (float, or __half with fp32 accumulation); SCH: 0 = bf16x3, 1 = f16mx8
+template <int SCH, typename ET, bool AVEC, bool KFULL>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_bf16x3_kernel(
     const ET *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
     ET *__restrict__ Y, int64_t ldy, int64_t M, int K, int F, int m_tiles, int n_wg, int k_steps)
@@ -77,7 +137,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_bf16x3_kernel(
         avalid[i] = true;
     }
     f32x16 acc[4][RN];
-    mainloop<ET, AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps, wm, nt0, n_tiles_total, lds, acc);
+    if constexpr (SCH == 0)
+        bx3::mainloop<ET, AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps, wm, nt0, n_tiles_total, lds, acc);
+    else
+        mx8::mainloop<ET, AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
 
 #ifndef GGCN_LAB_NO_STORE
     const bool full_rows = m0 + BM <= M;  // workgroup-uniform: the row guard only exists in the last tile
@@ -109,7 +172,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_bf16x3_kernel(
 #endif
 }
 
-template <typename ET>
+template <int SCH, typename ET>
 int launch_linear(const ET *X, int64_t ldx, const void *wpack, ET *Y, int64_t ldy, int64_t M, int K, int F,
                   hipStream_t st)
 {
@@ -125,7 +188,7 @@ int launch_linear(const ET *X, int64_t ldx, const void *wpack, ET *Y, int64_t ld
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_linear(bf16x3): M too large");
     const char *wp = static_cast<const char *>(wpack);
 #define GGCN_LAUNCH(AV, KF)                                                                                     \
-    hipLaunchKernelGGL((linear_bf16x3_kernel<ET, AV, KF>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, \
+    hipLaunchKernelGGL((linear_bf16x3_kernel<SCH, ET, AV, KF>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, \
                        wp, Y, ldy, M, K, F, (int)m_tiles, n_wg, k_steps)
     if (avec && kfull) GGCN_LAUNCH(true, true);
     else if (avec) GGCN_LAUNCH(true, false);
@@ -136,15 +199,16 @@ int launch_linear(const ET *X, int64_t ldx, const void *wpack, ET *Y, int64_t ld
 
 }  // namespace
 
-size_t weight_pack_bytes(int K, int F)
+size_t weight_pack_bytes(int K, int F, int precision)
 {
     if (K <= 0 || F <= 0) return 0;
-    const size_t k_steps = (size_t)bx3::round_up(K, bx3::BK) / bx3::KSTEP;  // whole 32-deep stages
+    const size_t stages = (size_t)bx3::round_up(K, bx3::BK) / bx3::BK;  // whole 32-deep stages
     const size_t n_tiles = (size_t)bx3::round_up(F, bx3::NT) / bx3::NT;
-    return n_tiles * k_steps * 2 * bx3::FRAG_BYTES;
+    if (precision == GGCN_PREC_F16MX8) return n_tiles * stages * mx8::STAGE_PACK_BYTES;
+    return n_tiles * stages * 2 * 2 * bx3::FRAG_BYTES;
 }
 
-int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, bool transposed, hipStream_t st)
+int weight_pack(const float *W, int64_t ldw, int K, int F, int precision, bool transposed, void *wpack, hipStream_t st)
 {
     if (!W || !wpack) return fail(GGCN_EINVAL, "ggcn_weight_pack: null pointer");
     if (K <= 0 || F <= 0 || ldw < (transposed ? K : F))
@@ -153,6 +217,17 @@ int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, bool tra
     const int k_steps = round_up(K, BK) / KSTEP;
     const int n_tiles = round_up(F, NT) / NT;
     if (k_steps > 65535) return fail(GGCN_EUNSUPPORTED, "ggcn_weight_pack: K too large");
+    if (precision == GGCN_PREC_F16MX8) {
+        const dim3 grid((unsigned)n_tiles, (unsigned)(k_steps / 2));
+        if (transposed)
+            hipLaunchKernelGGL(weight_pack_mx8_kernel<true>, grid, dim3(64), 0, st, W, ldw, K, F, k_steps / 2,
+                               static_cast<char *>(wpack));
+        else
+            hipLaunchKernelGGL(weight_pack_mx8_kernel<false>, grid, dim3(64), 0, st, W, ldw, K, F, k_steps / 2,
+                               static_cast<char *>(wpack));
+        return check_launch("ggcn_weight_pack(f16mx8)");
+    }
+    if (precision != GGCN_PREC_BF16X3) return fail(GGCN_EINVAL, "ggcn_weight_pack: precision %d has no packed image", precision);
     if (transposed)
         hipLaunchKernelGGL(weight_pack_kernel<true>, dim3((unsigned)n_tiles, (unsigned)k_steps), dim3(128), 0, st, W,
                            ldw, K, F, k_steps, static_cast<bf16x8 *>(wpack));
@@ -162,16 +237,20 @@ int weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, bool tra
     return check_launch("ggcn_weight_pack");
 }
 
-int linear_bf16x3(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy, int64_t M,
-                  int K, int F, hipStream_t st)
+int linear_packed(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy, int64_t M,
+                  int K, int F, int precision, hipStream_t st)
 {
-    return launch_linear<float>(X, ldx, wpack, Y, ldy, M, K, F, st);
+    if (precision == GGCN_PREC_F16MX8) return launch_linear<1, float>(X, ldx, wpack, Y, ldy, M, K, F, st);
+    return launch_linear<0, float>(X, ldx, wpack, Y, ldy, M, K, F, st);
 }
 
-int linear_bf16x3_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M,
-                    int K, int F, hipStream_t st)
+int linear_packed_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M,
+                    int K, int F, int precision, hipStream_t st)
 {
-    return launch_linear<__half>(static_cast<const __half *>(X), ldx, wpack, static_cast<__half *>(Y), ldy, M, K, F, st);
+    const __half *x = static_cast<const __half *>(X);
+    __half *y = static_cast<__half *>(Y);
+    if (precision == GGCN_PREC_F16MX8) return launch_linear<1, __half>(x, ldx, wpack, y, ldy, M, K, F, st);
+    return launch_linear<0, __half>(x, ldx, wpack, y, ldy, M, K, F, st);
 }
 
 }  // namespace ggcn

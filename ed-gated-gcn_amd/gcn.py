@@ -94,10 +94,10 @@ class _GatedLayerFunction(torch.autograd.Function):
             dx = dw = db = None
             if need[0]:
                 dx = torch.empty(B * T, K, dtype=torch.float32, device=dev)
-                if layer.precision == "bf16x3":
+                if layer.precision in _capi.PACKED:
                     pack_t = layer._packed_weight(lib, st, transposed=True)
                     _capi.check(lib.ggcn_linear(_capi.ptr(dh), F, None, 0, _capi.ptr(pack_t), _capi.ptr(dx), K,
-                                                B * T, F, K, _capi.PREC["bf16x3"], st), "ggcn_linear(dX)")
+                                                B * T, F, K, _capi.PREC[layer.precision], st), "ggcn_linear(dX)")
                 else:
                     wt = weight.detach().t().contiguous()
                     _capi.check(lib.ggcn_linear(_capi.ptr(dh), F, _capi.ptr(wt), K, None, _capi.ptr(dx), K,
@@ -129,7 +129,8 @@ class GraphConvolution(nn.Module):
             self.bias = nn.Parameter(torch.empty(out_features, dtype=torch.float32))
         else:
             self.register_parameter("bias", None)
-        # arithmetic of the dense linear: "bf16x3" (fast, ~1e-5 abs) or "fp32" (exact fp32 MFMA)
+        # arithmetic of the dense linear: "bf16x3" (3 bf16 MFMAs per product, ~1e-5 abs), "f16mx8" (fp16 MFMA
+        # + one block-scaled fp8 correction MFMA, needs |x|,|w| < 65504) or "fp32" (exact fp32 MFMA)
         self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "bf16x3")
         # one-launch layer (fused_layer.hip) when the batch allows it: T <= 32, binary adjacency, bf16x3
         self.fused = bool(getattr(opt, "ggcn_fused", True)) and os.environ.get("GGCN_FUSED", "1") != "0"
@@ -144,22 +145,23 @@ class GraphConvolution(nn.Module):
         return "in_features=%d, out_features=%d, bias=%s, precision=%s" % (
             self.in_features, self.out_features, self.bias is not None, self.precision)
 
-    # -- weight image for the bf16x3 linear, rebuilt only when the weight changes ----------
+    # -- weight image for the split-precision linears, rebuilt only when the weight changes ----------
     def _packed_weight(self, lib, stream, transposed=False):
-        """bf16 hi/lo image of W (forward) or W^T (backward's dX), rebuilt when W changes."""
+        """MFMA-order image of W (forward) or W^T (backward's dX), rebuilt when W or the precision changes."""
         w = self.weight
-        key = (w.data_ptr(), w._version, w.device)
+        prec = _capi.PREC[self.precision if self.precision in _capi.PACKED else "bf16x3"]
+        key = (w.data_ptr(), w._version, w.device, prec)
         slot = 1 if transposed else 0
         if self._pack is None:
             self._pack, self._pack_key = [None, None], [None, None]
         if self._pack[slot] is None or self._pack_key[slot] != key:
             K, F = (self.out_features, self.in_features) if transposed else (self.in_features, self.out_features)
-            pack = torch.empty(lib.ggcn_weight_pack_bytes(K, F), dtype=torch.uint8, device=w.device)
+            pack = torch.empty(lib.ggcn_weight_pack_bytes(K, F, prec), dtype=torch.uint8, device=w.device)
             wc = w.detach()
             if not wc.is_contiguous():
                 wc = wc.contiguous()
-            fn = lib.ggcn_weight_pack_t if transposed else lib.ggcn_weight_pack
-            _capi.check(fn(_capi.ptr(wc), self.out_features, K, F, _capi.ptr(pack), stream), "ggcn_weight_pack")
+            _capi.check(lib.ggcn_weight_pack(_capi.ptr(wc), self.out_features, K, F, prec, 1 if transposed else 0,
+                                             _capi.ptr(pack), stream), "ggcn_weight_pack")
             self._pack[slot], self._pack_key[slot] = pack, key
         return self._pack[slot]
 
@@ -183,14 +185,15 @@ class GraphConvolution(nn.Module):
         # float16 features (BASELINE configs[3]) are an extension: the reference itself raises a
         # dtype mismatch for half inputs.  Weights, bias, gates stay float32.
         _require_gpu_f32("text", text, allow_half=True)
-        if text.dtype == torch.float16 and self.precision != "bf16x3":
-            raise RuntimeError("float16 features need precision='bf16x3' (the exact-fp32 linear is fp32 only)")
+        if text.dtype == torch.float16 and self.precision not in _capi.PACKED:
+            raise RuntimeError("float16 features need precision='bf16x3' or 'f16mx8' (the exact-fp32 linear is "
+                               "fp32 only)")
         if text.dim() != 3 or text.shape[2] != self.in_features:
             raise RuntimeError("text must be [B,T,%d], got %s" % (self.in_features, tuple(text.shape)))
         if self.weight.device != text.device:
             raise RuntimeError("weight is on %s but text is on %s" % (self.weight.device, text.device))
         if self.precision not in _capi.PREC:
-            raise RuntimeError("unknown precision %r (use 'bf16x3' or 'fp32')" % (self.precision,))
+            raise RuntimeError("unknown precision %r (use 'bf16x3', 'f16mx8' or 'fp32')" % (self.precision,))
 
     def linear(self, x2d):
         """``hidden = text @ W`` (``gcn.py:34``) on [N,in] -> [N,out]."""
@@ -202,13 +205,14 @@ class GraphConvolution(nn.Module):
             if x2d.dtype == torch.float16:
                 pack = self._packed_weight(lib, st)  # noqa
                 _capi.check(lib.ggcn_linear_h(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack), _capi.ptr(y),
-                                              y.stride(0), x2d.shape[0], self.in_features, self.out_features, st),
+                                              y.stride(0), x2d.shape[0], self.in_features, self.out_features,
+                                              _capi.PREC[self.precision], st),
                             "ggcn_linear_h")
                 return y
             w = self.weight.detach()
             if not w.is_contiguous():
                 w = w.contiguous()
-            pack = self._packed_weight(lib, st) if self.precision == "bf16x3" else None
+            pack = self._packed_weight(lib, st) if self.precision in _capi.PACKED else None
             _capi.check(lib.ggcn_linear(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(w), w.stride(0),
                                         _capi.ptr(pack), _capi.ptr(y), y.stride(0), x2d.shape[0],
                                         self.in_features, self.out_features, _capi.PREC[self.precision], st),
@@ -250,7 +254,7 @@ class GraphConvolution(nn.Module):
                     raise RuntimeError("%s must be a contiguous [B,F]=[%d,%d] tensor, got %s"
                                        % (name, B, F, tuple(g.shape)))
         half = text.dtype == torch.float16
-        use_fused = (self.fused and self.precision == "bf16x3" and csr.rowmask is not None
+        use_fused = (self.fused and self.precision in _capi.PACKED and csr.rowmask is not None
                      and csr.is_binary and not half)
         hidden = None if use_fused else self.linear(x2d)
         with torch.cuda.device(dev):
@@ -265,7 +269,8 @@ class GraphConvolution(nn.Module):
                                                  _capi.ptr(csr.rowmask), _capi.ptr(bias), B, T,
                                                  self.in_features, F, _capi.ptr(store_gate),
                                                  _capi.ptr(pool_gate_a), _capi.ptr(pool_gate_b), _capi.ptr(out),
-                                                 F, _capi.ptr(pa), _capi.ptr(pb), st), "ggcn_layer_fused")
+                                                 F, _capi.ptr(pa), _capi.ptr(pb), _capi.PREC[self.precision], st),
+                            "ggcn_layer_fused")
                 return (None if out is None else out.view(B, T, F)), pa, pb
             agg = lib.ggcn_aggregate_h if half else lib.ggcn_aggregate
             _capi.check(agg(_capi.ptr(hidden), hidden.stride(0), _capi.ptr(csr.rowptr),

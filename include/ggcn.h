@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 1
+#define GGCN_ABI_VERSION 2
 
 typedef void *ggcn_stream_t;
 
@@ -66,7 +66,11 @@ enum ggcn_csr_flags {
 enum ggcn_precision {
     GGCN_PREC_BF16X3 = 0,  /* fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per
                               product, fp32 accumulate: |err| ~ 2^-16 |x||w| per product */
-    GGCN_PREC_FP32 = 1     /* v_mfma_f32_32x32x2_f32: a k-ordered fp32 FMA chain, exact fp32 */
+    GGCN_PREC_FP32 = 1,    /* v_mfma_f32_32x32x2_f32: a k-ordered fp32 FMA chain, exact fp32 */
+    GGCN_PREC_F16MX8 = 2   /* operands split into fp16 hi + residual; hi.hi on the fp16 MFMA, both cross
+                              terms in ONE block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4):
+                              2/3 of bf16x3's matrix-core time, |err| ~ 2^-15 |x||w| per product.
+                              Needs |x|, |w| < 65504 (fp16 range; larger values saturate to inf) */
 };
 
 int ggcn_abi_version(void);
@@ -102,11 +106,15 @@ int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
 
 /* ---- dense linear ----------------------------------------------------------
  * Replaces models/gcn.py:34: Y[M,F] = X[M,K] . W[K,F]  (W is in x out, gcn.py:18).
- * GGCN_PREC_BF16X3 needs `wpack`, the bf16 hi/lo image of W made once per weight
- * update by ggcn_weight_pack (ggcn_weight_pack_bytes(K,F) bytes); GGCN_PREC_FP32
- * reads W itself and ignores wpack. */
-size_t ggcn_weight_pack_bytes(int K, int F);
-int ggcn_weight_pack(const float *W, int64_t ldw, int K, int F, void *wpack, ggcn_stream_t stream);
+ * GGCN_PREC_BF16X3 and GGCN_PREC_F16MX8 need `wpack`, the split image of W in MFMA
+ * fragment order, made once per weight update by ggcn_weight_pack for THAT precision
+ * (ggcn_weight_pack_bytes(K,F,precision) bytes; the two images differ); GGCN_PREC_FP32
+ * reads W itself and ignores wpack.  transposed != 0 packs W^T instead: W is then
+ * [F,K] row-major with ldw >= K, the image is that of the [K,F] matrix W^T (the dX
+ * linear of the backward pass, train.py:120, uses it with the forward's weight). */
+size_t ggcn_weight_pack_bytes(int K, int F, int precision);
+int ggcn_weight_pack(const float *W, int64_t ldw, int K, int F, int precision, int transposed,
+                     void *wpack, ggcn_stream_t stream);
 int ggcn_linear(const float *X, int64_t ldx, const float *W, int64_t ldw, const void *wpack,
                 float *Y, int64_t ldy, int64_t M, int K, int F, int precision,
                 ggcn_stream_t stream);
@@ -135,9 +143,9 @@ int ggcn_aggregate(const float *Hd, int64_t ldh,
  *   dH = A^T.(D.dY)   ggcn_aggregate_t on the TRANSPOSED adjacency (CSR of adj^T: rows = source
  *                     nodes), src_scale = the 1/(rowsum+1) of the ORIGINAL rows from
  *                     ggcn_inv_denominators;  out[j] = sum_e vals_t[e]*src_scale[colidx_t[e]]*G[colidx_t[e]]
- *   dX = dH.W^T       ggcn_linear with the image made by ggcn_weight_pack_t
- *                     (packs the transpose of the stored [K_stored x ldw] matrix: the packed
- *                     operand has K = F_layer rows and F = K_layer columns)
+ *   dX = dH.W^T       ggcn_linear with the image made by ggcn_weight_pack(transposed = 1)
+ *                     (packs the transpose of the stored matrix: the packed operand has
+ *                     K = F_layer rows and F = K_layer columns)
  *   dW = X^T.dH       ggcn_dweight: exact fp32 MFMA, split over the node rows, deterministic
  *                     (workspace: ggcn_dweight_workspace_bytes(N, K, F) bytes)
  *   db = sum_rows dY  a plain column sum on the caller's side. */
@@ -155,7 +163,6 @@ int ggcn_gate_pool_backward(const float *out, int64_t ldo,
 size_t ggcn_dweight_workspace_bytes(int64_t n_rows, int K, int F);
 int ggcn_dweight(const float *X, int64_t ldx, const float *dH, int64_t ldg, int64_t n_rows, int K, int F,
                  float *dW, int64_t lddw, void *workspace, ggcn_stream_t stream);
-int ggcn_weight_pack_t(const float *W, int64_t ldw, int K, int F, void *wpack, ggcn_stream_t stream);
 int ggcn_inv_denominators(const int32_t *rowptr, const float *vals, int64_t n_rows, float *inv,
                           ggcn_stream_t stream);
 int ggcn_aggregate_t(const float *G, int64_t ldg,
@@ -170,7 +177,7 @@ int ggcn_aggregate_t(const float *G, int64_t ldg,
  * on fp16-rounded inputs.  An fp16 value splits exactly into two bf16 terms, so the linear uses
  * the same three-product scheme as GGCN_PREC_BF16X3. */
 int ggcn_linear_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy,
-                  int64_t M, int K, int F, ggcn_stream_t stream);
+                  int64_t M, int K, int F, int precision, ggcn_stream_t stream);
 int ggcn_aggregate_h(const void *Hd, int64_t ldh,
                      const int32_t *rowptr, const int32_t *colidx, const float *vals,
                      const float *bias, int B, int T, int F,
@@ -180,15 +187,16 @@ int ggcn_aggregate_h(const void *Hd, int64_t ldh,
 
 /* ---- one whole gated layer in one launch (graphs of <= 32 nodes, binary adjacency) ----
  * Replaces models/gcn.py:34-45 + models/bert_amir5.py:627-640 without materialising
- * `hidden`: the bf16x3 linear's accumulator tile (one graph x 32 features) is multiplied by
+ * `hidden`: the linear's accumulator tile (one graph x 32 features) is multiplied by
  * the graph's 0/1 adjacency with a second MFMA, then divided, biased, gated, pooled and
  * stored.  Same outputs and argument meaning as ggcn_linear(GGCN_PREC_BF16X3) followed by
- * ggcn_aggregate; X is [B*T, K], wpack from ggcn_weight_pack(K, F), rowmask uint32[B*T]. */
+ * ggcn_aggregate; X is [B*T, K], wpack from ggcn_weight_pack(K, F, precision), rowmask
+ * uint32[B*T]; precision is GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8. */
 int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask,
                      const float *bias, int B, int T, int K, int F,
                      const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
                      float *out, int64_t ldo, float *pool_a, float *pool_b,
-                     ggcn_stream_t stream);
+                     int precision, ggcn_stream_t stream);
 
 /* ---- gate-diversity regulariser --------------------------------------------
  * Replaces models/bert_amir5.py:638: *xy = mean_b sum_f x1[b,f]*y1[b,f].

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import csr_ref, ref_dense  # noqa: E402  (tests may use the oracle)
 
-TOL = {"fp32": 2e-5, "bf16x3": 1e-4}
+TOL = {"fp32": 2e-5, "bf16x3": 1e-4, "f16mx8": 1e-4}
 
 
 @pytest.fixture(scope="module")
@@ -34,9 +34,9 @@ def pkg():
     return p
 
 
-# (precision, fused): the one-launch layer kernel only exists for bf16x3
-MODES = [("fp32", False), ("bf16x3", False), ("bf16x3", True)]
-MODE_IDS = ["fp32", "bf16x3-unfused", "bf16x3-fused"]
+# (precision, fused): the one-launch layer kernel exists for the two split-precision linears
+MODES = [("fp32", False), ("bf16x3", False), ("bf16x3", True), ("f16mx8", False), ("f16mx8", True)]
+MODE_IDS = ["fp32", "bf16x3-unfused", "bf16x3-fused", "f16mx8-unfused", "f16mx8-fused"]
 
 
 def _layer(pkg, dev, w, b, precision, fused=True):
@@ -178,7 +178,7 @@ def test_gated_block_vs_oracle(pkg, dev, precision, fused, B, T, H, padded):
     assert abs(float(r["xy"]) - float(ref["xy"])) <= 1e-4 * max(1.0, abs(float(ref["xy"])))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx8"])
 @pytest.mark.parametrize("M,K,F", [(256, 768, 768), (1000, 300, 300), (33, 17, 5), (513, 768, 34), (7, 9216, 256)])
 def test_linear_vs_float64(pkg, dev, precision, M, K, F):
     """gcn.py:34 alone, against a float64 product (odd shapes hit every edge/tail path)."""
@@ -190,14 +190,16 @@ def test_linear_vs_float64(pkg, dev, precision, M, K, F):
         y = m.linear(torch.from_numpy(x).to(dev)).cpu().numpy()
     ref = x.astype(np.float64) @ w.astype(np.float64)
     scale = np.sqrt(K) * np.sqrt(np.mean(x.astype(np.float64) ** 2) * np.mean(w.astype(np.float64) ** 2))
-    # fp32: a K-long fp32 FMA chain (~sqrt(K)*2^-24 rms, a few sigma at the max); bf16x3: ~2^-16 per product
-    bound = {"fp32": 1e-5, "bf16x3": 3e-5}[precision] * max(1.0, scale)
+    # fp32: a K-long fp32 FMA chain (~sqrt(K)*2^-24 rms, a few sigma at the max); bf16x3: ~2^-16 per product;
+    # f16mx8: the fp8 correction leaves ~2^-15 per product
+    bound = {"fp32": 1e-5, "bf16x3": 3e-5, "f16mx8": 6e-5}[precision] * max(1.0, scale)
     assert np.max(np.abs(y - ref)) <= bound
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
 @pytest.mark.parametrize("B,T,H", [(130, 32, 768), (33, 31, 256), (6, 7, 96)])
-def test_fused_layer_equals_unfused(pkg, dev, B, T, H):
-    """Same main loop, same bf16 planes: the one-launch layer and linear+aggregate differ only by
+def test_fused_layer_equals_unfused(pkg, dev, B, T, H, precision):
+    """Same main loop, same operand planes: the one-launch layer and linear+aggregate differ only by
     the two-plane (2^-17) MFMA aggregation and one reciprocal per node."""
     from ed_gated_gcn_amd import synth
     rng = np.random.default_rng(B)
@@ -209,7 +211,7 @@ def test_fused_layer_equals_unfused(pkg, dev, B, T, H):
     a = torch.from_numpy(adj).to(dev)
     outs = []
     for fused in (True, False):
-        m = _layer(pkg, dev, w, b, "bf16x3", fused)
+        m = _layer(pkg, dev, w, b, precision, fused)
         with torch.no_grad():
             outs.append(m.forward_gated(x, a, store_gate=g2, pool_gate_a=g1, pool_gate_b=g2,
                                         want_pool_a=True, want_pool_b=True))
@@ -227,7 +229,7 @@ def test_unaligned_and_strided_inputs(pkg, dev):
     w, b = synth.layer_params(K, F, seed=4)
     ref = ref_dense.graph_convolution(torch.from_numpy(x_big[:, :, :K].copy()), torch.from_numpy(adj),
                                       torch.from_numpy(w), torch.from_numpy(b)).numpy()
-    for precision in ("fp32", "bf16x3"):
+    for precision in ("fp32", "bf16x3", "f16mx8"):
         m = _layer(pkg, dev, w, b, precision)
         with torch.no_grad():
             out = m(torch.from_numpy(x_big).to(dev)[:, :, :K], torch.from_numpy(adj).to(dev))
@@ -334,15 +336,42 @@ def test_config4_long_document_sample(pkg, dev):
     w, b = synth.layer_params(H, H, seed=5)
     ref = ref_dense.graph_convolution(torch.from_numpy(x), torch.from_numpy(adj), torch.from_numpy(w),
                                       torch.from_numpy(b)).numpy()
-    for precision in ("fp32", "bf16x3"):
+    for precision in ("fp32", "bf16x3", "f16mx8"):
         m = _layer(pkg, dev, w, b, precision)
         with torch.no_grad():
             out = m(torch.from_numpy(x).to(dev), torch.from_numpy(adj).to(dev))
         np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=TOL[precision])
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["unfused", "fused"])
+def test_f16mx8_is_deterministic_and_degrades_gracefully(pkg, dev, fused):
+    """Same inputs -> same bits (no atomics on the value path, no races in the staged pipeline), and
+    activations far outside the fp8 window of the correction (|x| > 448 saturates it, |x| < 2^-9 flushes it)
+    still give a finite result with the accuracy of the fp16 product (2^-11 relative per factor)."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(77)
+    B, T, H = 64, 32, 256
+    adj = torch.from_numpy(synth.dependency_batch(B, T, 4.0, seed=2)).to(dev)
+    w, b = synth.layer_params(H, H, seed=6)
+    m = _layer(pkg, dev, w, b, "f16mx8", fused)
+    x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        first = m(x, adj).clone()
+        for _ in range(5):
+            assert torch.equal(m(x, adj), first)
+    for scale in (3000.0, 2.0 ** -14):
+        xs = x * scale
+        ref = ref_dense.graph_convolution(xs.cpu(), adj.cpu(), torch.from_numpy(w), None)
+        mz = _layer(pkg, dev, w, None, "f16mx8", fused)
+        with torch.no_grad():
+            out = mz(xs, adj).cpu()
+        assert torch.isfinite(out).all()
+        assert float((out - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
 @pytest.mark.parametrize("B,T,H", [(4, 512, 1024), (3, 100, 200), (5, 31, 72), (2, 9, 13)])
-def test_fp16_features_config4(pkg, dev, B, T, H):
+def test_fp16_features_config4(pkg, dev, B, T, H, precision):
     """BASELINE.json configs[3]: fp16 features, fp32 accumulation.  The reference cannot run half
     inputs, so the oracle is its fp32 forward on the fp16-ROUNDED inputs; the HIP path
     additionally rounds `hidden` and the output to fp16 -> atol 2e-3."""
@@ -354,7 +383,7 @@ def test_fp16_features_config4(pkg, dev, B, T, H):
     w, b = synth.layer_params(H, H, seed=5)
     ref = ref_dense.graph_convolution(x16.float(), torch.from_numpy(adj), torch.from_numpy(w), torch.from_numpy(b))
     ref_gated = (ref * g[:, None, :])
-    m = _layer(pkg, dev, w, b, "bf16x3")
+    m = _layer(pkg, dev, w, b, precision)
     with torch.no_grad():
         out, pa, _ = m.forward_gated(x16.to(dev), torch.from_numpy(adj).to(dev), store_gate=g.to(dev),
                                      pool_gate_a=g.to(dev), want_pool_a=True)

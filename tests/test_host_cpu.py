@@ -41,8 +41,10 @@ def test_binding_covers_every_declared_symbol_and_abi_matches():
     lib = pkg.load_library()
     assert lib.ggcn_abi_version() == _capi.ABI_VERSION
     # pure host helpers (no GPU needed)
-    assert lib.ggcn_weight_pack_bytes(768, 768) == 768 * 768 * 2 * 2
-    assert lib.ggcn_weight_pack_bytes(300, 300) == 320 * 320 * 2 * 2
+    assert lib.ggcn_weight_pack_bytes(768, 768, 0) == 768 * 768 * 2 * 2
+    assert lib.ggcn_weight_pack_bytes(300, 300, 0) == 320 * 320 * 2 * 2
+    # f16mx8: per (32 columns x 32 k) 2 KiB fp16 + 2 KiB fp8 (hi and residual) + 256 B block scales
+    assert lib.ggcn_weight_pack_bytes(768, 768, 2) == 24 * 24 * 4352
     assert lib.ggcn_csr_workspace_bytes(131072) == 128 * 4
     assert lib.ggcn_overlap_workspace_bytes(4096) == 4096 * 4
 
@@ -55,7 +57,7 @@ def test_bad_arguments_return_codes_not_crashes():
     assert rc == 1
     rc = lib.ggcn_csr_from_dense(None, 0, 1, 4, 16, 4, 1, None, None, None, 16, None, None, None, None)
     assert rc == 1
-    rc = lib.ggcn_layer_fused(None, 8, None, None, None, 1, 4, 8, 8, None, None, None, None, 8, None, None, None)
+    rc = lib.ggcn_layer_fused(None, 8, None, None, None, 1, 4, 8, 8, None, None, None, None, 8, None, None, 0, None)
     assert rc == 1
     rc = lib.ggcn_csr_rowmask(None, None, 1, 4, None, None)
     assert rc == 1

@@ -25,7 +25,7 @@ ref = block64(x.double(), t(adj).double(), g1.double(), g2.double(), t(w1).doubl
               t(w2).double(), t(b2).double())
 f32 = ref_dense.gated_block(x, t(adj).float(), g1, g2, t(w1), t(b1), t(w2), t(b2))
 print("%-22s %s" % ("torch-cpu fp32", "  ".join("%s %.2e" % (k, float((f32[k].double() - ref[k]).abs().max())) for k in ("gcn1", "x", "out"))))
-for prec, fused in (("fp32", False), ("bf16x3", False), ("bf16x3", True)):
+for prec, fused in (("fp32", False), ("bf16x3", False), ("bf16x3", True), ("f16mx8", False), ("f16mx8", True)):
     ls = []
     for w, b in ((w1, b1), (w2, b2)):
         m = pkg.GraphConvolution(H, H, None).to(dev); m.precision = prec; m.fused = fused

@@ -58,21 +58,23 @@ def time_variants(what, names):
         names = sorted(f[len("libggcn_"):-3] for f in os.listdir(LAB) if f.endswith(".so"))
     libs = {}
     for n in names:
-        path = os.path.join(LAB, "libggcn_%s.so" % n) if n != "main" else pkg.lib_path()
+        base = n.split("@")[0]  # "name@mx8" times the f16mx8 precision of that build
+        path = os.path.join(LAB, "libggcn_%s.so" % base) if base != "main" else pkg.lib_path()
         lib = ctypes.CDLL(path)
         for fn, (res, args) in _capi.PROTOTYPES.items():
             if hasattr(lib, fn):
                 getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
-        pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H), dtype=torch.uint8, device=dev)
-        assert lib.ggcn_weight_pack(_capi.ptr(w), H, H, H, _capi.ptr(pack), None) == 0
-        libs[n] = (lib, pack)
+        prec = 2 if n.endswith("@mx8") else 0
+        pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H, prec), dtype=torch.uint8, device=dev)
+        assert lib.ggcn_weight_pack(_capi.ptr(w), H, H, H, prec, 0, _capi.ptr(pack), None) == 0
+        libs[n] = (lib, pack, prec)
     st = _capi.stream_of(dev)
     p = _capi.ptr
 
     def run(n):
-        lib, pack = libs[n]
+        lib, pack, prec = libs[n]
         if what == "linear":
-            rc = lib.ggcn_linear(p(x), H, p(w), H, p(pack), p(y), H, N, H, H, 0, st)
+            rc = lib.ggcn_linear(p(x), H, p(w), H, p(pack), p(y), H, N, H, H, prec, st)
         elif what == "linear_fp32":
             rc = lib.ggcn_linear(p(x), H, p(w), H, None, p(y), H, N, H, H, 1, st)
         elif what == "aggregate":
@@ -80,7 +82,7 @@ def time_variants(what, names):
                                     p(out), H, p(pa), p(pb), st)
         elif what == "fused":
             rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
-                                      p(out), H, p(pa), p(pb), st)
+                                      p(out), H, p(pa), p(pb), prec, st)
         else:
             raise SystemExit("unknown target " + what)
         assert rc == 0, lib.ggcn_last_error()
