@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--tokens", type=int, default=32)
     ap.add_argument("--hidden", type=int, default=768)
     ap.add_argument("--degree", type=float, default=4.0)
-    ap.add_argument("--precision", default=os.environ.get("GGCN_PRECISION", "bf16x3"), choices=["bf16x3", "fp32"])
+    ap.add_argument("--precision", default=os.environ.get("GGCN_PRECISION", "f16mx8"),
+                    choices=["f16mx8", "bf16x3", "fp32"],
+                    help="arithmetic of the dense linear; all three meet the 1e-4 parity gate (tests/test_gpu_parity.py)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --graphs per GPU; strong: --graphs in total, sharded (BASELINE configs[2])")
     ap.add_argument("--unfused", action="store_true", help="force linear + aggregate (2 launches per layer)")
@@ -218,8 +220,13 @@ def main():
     fwd_bytes = 2 * synth.algorithmic_bytes_per_layer(B, T, H, nnz)
     lin_flops = 2.0 * N * H * H                       # algorithmic flops of gcn.py:34 per launch
     agg_flops = 2.0 * nnz * H                         # gcn.py:41 on the non-zeros
-    lin_peak = MFMA_BF16_PEAK_TF if args.precision == "bf16x3" else MFMA_F32_PEAK_TF
-    fused_path = gc1.fused and args.precision == "bf16x3" and csr.rowmask is not None and csr.is_binary
+    lin_peak = MFMA_F32_PEAK_TF if args.precision == "fp32" else MFMA_BF16_PEAK_TF
+    fused_path = gc1.fused and args.precision in ("bf16x3", "f16mx8") and csr.rowmask is not None and csr.is_binary
+    issue_note = {"bf16x3": "the bf16x3 linear issues 3 bf16 MFMA flops per algorithmic flop, so its ceiling on this "
+                            "peak is 1/3 (833 TFLOP/s)",
+                  "f16mx8": "the f16mx8 linear spends 128 matrix-pipe cycles per 32x32x32 block (64 fp16 + 64 "
+                            "block-scaled fp8) where plain bf16 spends 64, so its ceiling on this peak is 1/2 "
+                            "(1250 TFLOP/s)"}.get(args.precision, "")
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch, if recorded
     measured = json.load(open(tpath)) if os.path.exists(tpath) else {}
@@ -227,14 +234,13 @@ def main():
     if fused_path:
         t_fused = t_layer_in_loop   # one kernel per layer launch: measured over the timed region itself
         tf = (lin_flops + agg_flops) / t_fused / 1e12
-        traffic = measured.get("layer_fused_kernel")
+        traffic = measured.get("layer_fused_kernel:" + args.precision, measured.get("layer_fused_kernel"))
         roofline = {"kernel": "layer_fused_kernel", "bound": "mfma", "achieved": tf, "peak": lin_peak,
                     "unit": "TFLOP/s", "frac": tf / lin_peak, "traffic": traffic, "avg_launch_us": t_fused * 1e6,
                     "algorithmic_flops_per_launch": lin_flops + agg_flops,
                     "algorithmic_bytes_per_launch": layer_bytes,
                     "hbm_GBps": layer_bytes / t_fused / 1e9, "hbm_frac": layer_bytes / t_fused / 1e9 / HBM_PEAK_GBS,
-                    "note": "achieved = algorithmic (2*N*K*F + 2*nnz*F) flops / launch; the bf16x3 linear issues 3 "
-                            "bf16 MFMA flops per algorithmic flop, so its ceiling on this peak is 1/3 (833 TFLOP/s)"}
+                    "note": "achieved = algorithmic (2*N*K*F + 2*nnz*F) flops / launch; " + issue_note}
         kernels["layer_fused"] = {"avg_launch_us": t_fused * 1e6, "algorithmic_tflops": tf, "launches_per_step": 2}
     else:
         with torch.no_grad():
@@ -273,7 +279,8 @@ def main():
             "metric": "gated_gcn_forward_edges_per_sec", "value": value, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 (bf16x3 MFMA split, fp32 accumulate)",
+            "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3 MFMA split, fp32 accumulate)",
+                      "f16mx8": "f32 (fp16 MFMA + block-scaled fp8 correction MFMA, fp32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: %d graphs/GPU x %d tokens, avg degree %g "
                                    "(nnz %d incl. self loops), hidden %d, 2 gated-GCN layers, fp32 in/out"

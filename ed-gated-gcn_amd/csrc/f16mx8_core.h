@@ -103,7 +103,16 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 
     float ra[NP][EPT];
     auto load_a_pass = [&](int i, int k0) {
+#ifdef GGCN_MX_LAB_AFIX  // timing probe: every stage reads the first 32 k of its rows (L1 hits)
+        k0 = 0;
+#endif
         const int gk = k0 + s_k;
+#ifdef GGCN_MX_LAB_TILED  // timing probe: X addressed as [row block][stage][128 rows][32 k] -> one contiguous 16 KiB per stage
+        if constexpr (AVEC) {
+            load16<AT>(arow[i] + (k0 / 32) * 4096 + s_k, ra[i]);
+            return;
+        }
+#endif
         if constexpr (AVEC) {
             load16<AT>(arow[i] + ((KFULL || gk < K) ? gk : 0), ra[i]);
         } else {
@@ -154,6 +163,9 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     }
     auto load_bf = [&](int st, f16x8 (&b0)[RN], f16x8 (&b1)[RN]) {  // fp16 fragments of both k-steps of stage st
         st = st < stages_packed ? st : stages_packed - 1;
+#ifdef GGCN_MX_LAB_BFIX  // timing probe: every stage reads the B image of stage 0 (L1 hits)
+        st = 0;
+#endif
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES;
@@ -163,6 +175,9 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     };
     auto load_bq = [&](int st, i32x8 (&b)[RN], int (&sc)[RN]) {  // MX operand + scales of stage st
         st = st < stages_packed ? st : stages_packed - 1;
+#ifdef GGCN_MX_LAB_BFIX
+        st = 0;
+#endif
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES + 2048 + lane * 16;  // lane * 32 in all
@@ -268,7 +283,9 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bq[1], acc[i][1], 0, 0, 0, scale_a, 0, sq[1]);
             GGCN_SB();
         }
+#ifndef GGCN_MX_LAB_NOBAR
         __syncthreads();
+#endif
     };
     int st = 0;
     for (; st + 1 < stages; st += 2) {

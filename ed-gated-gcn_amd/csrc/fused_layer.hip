@@ -43,8 +43,19 @@ __device__ __forceinline__ void split2(const f32x16 &acc, bf16x8 (&frag)[2][2])
 }
 
 // FULLT: T == 32 and B % 4 == 0 (every row of every tile is a real node): drops every guard.
+#ifdef GGCN_LAB_TRACE  // timeline probe: per workgroup {block, HW_ID, XCC_ID, t0, t1, t2, t3} in 10 ns ticks
+__device__ unsigned long long ggcn_trace_buf[8192 * 8];
+#define GGCN_TRACE(slot)                                                              \
+    do {                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) ggcn_trace_buf[blockIdx.x * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define GGCN_TRACE(slot) do { } while (0)
+#endif
+
 // SCH: 0 = bf16x3 main loop, 1 = f16mx8 (f16mx8_core.h)
-template <int SCH, bool AVEC, bool KFULL, bool FULLT>
+// VST: the [N,F] output leaves through LDS as 16-byte row stores (needs F, ldo multiples of 4 and a 16-byte aligned out)
+template <int SCH, bool AVEC, bool KFULL, bool FULLT, bool VST>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
     const float *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
     const uint32_t *__restrict__ rowmask, const float *__restrict__ bias, int B, int T, int K, int F,
@@ -59,6 +70,17 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
 #endif
     int g_tile, n_wgi;
     if (!tile_of_block(blockIdx.x, g_tiles, n_wg, g_tile, n_wgi)) return;
+#ifdef GGCN_LAB_REVERSE2  // probe: the layer that applies a store gate (layer 2) walks the row blocks backwards
+    if (store_gate) g_tile = g_tiles - 1 - g_tile;
+#endif
+#ifdef GGCN_LAB_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        ggcn_trace_buf[blockIdx.x * 8 + 0] = blockIdx.x;
+        ggcn_trace_buf[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_REG_HW_ID
+        ggcn_trace_buf[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // HW_REG_XCC_ID
+    }
+    GGCN_TRACE(3);
+#endif
 #if defined(GGCN_STAGGER)
     // Two workgroups share a CU and run the same program; started together they stay in lockstep
     // and reach their (MFMA-free) epilogues at the same time.  Delay the second resident set of the
@@ -89,6 +111,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
         avalid[i] = (g < B) && (FULLT || r < T);
         const int64_t node = avalid[i] ? (int64_t)g * T + r : 0;  // clamped, zeroed by the select
         arow[i] = X + node * ldx;
+#ifdef GGCN_MX_LAB_TILED
+        arow[i] = X + (int64_t)g_tile * 128 * ldx + row * 32;
+#endif
     }
     // this lane's adjacency row (node lane&31) of each of the 4 graphs: in flight under the main loop
     uint32_t mask[4];
@@ -101,11 +126,20 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
     }
 
     f32x16 acc[4][RN];
+    GGCN_TRACE(4);
+#if defined(GGCN_LAB_PHASE)  // timing probe (wrong results): half the K loop for the odd row blocks of the first
+                             // (PHASE=1) or the last (PHASE=2, control) round: does a half-period phase shift pay?
+    const bool lab_short = (g_tile & 1) && (GGCN_LAB_PHASE == 1 ? blockIdx.x < 512 : blockIdx.x + 512 >= gridDim.x);
+    const int K_loop = lab_short ? K / 2 : K;
+#else
+    const int K_loop = K;
+#endif
     if constexpr (SCH == 0)
-        bx3::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, k_steps, wm, nt0, n_tiles_total, lds, acc);
+        bx3::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K_loop, k_steps, wm, nt0, n_tiles_total, lds, acc);
     else
-        mx8::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
+        mx8::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K_loop, k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
 
+    GGCN_TRACE(5);
     const int c = lane & 31, h = lane >> 5;
 
     // bias and the gates of the 4 graphs x 2 column tiles: all loads issued together, one latency
@@ -126,6 +160,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
         }
     }
     const int lane_off = 4 * h * ldo + c;  // this lane's element inside a (graph, column tile) block
+    // the A buffers are free after the main loop's last barrier: 8 KiB per wavefront = 32 rows x 64 columns
+    float *stage_lds = reinterpret_cast<float *>(lds) + wave * (32 * 64);
     const int perm_base = 16 * h;          // ds_bpermute byte address of lane 4h (+ 4*row0 per register)
 
 #pragma unroll
@@ -180,8 +216,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
                 const float v = y[r] * rinv[r] + vb[j];   // gcn.py:41,43
+                if (VST) {
+                    // staged for the 16-byte row stores below; columns of the rows with bit 2 set are
+                    // swapped between the two 32-column halves so that h = 0 / 1 hit different banks
+                    stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = v * sg;
+                }
                 if (FULLT || row0 + 4 * h < T) {
-                    if (tile && col_ok[j]) tile[lane_off + row0 * ldo] = v * sg;  // bert_amir5.py:626 / :639
+                    if (!VST && tile && col_ok[j]) tile[lane_off + row0 * ldo] = v * sg;  // bert_amir5.py:626 / :639
                     vmax = fmaxf(vmax, v);
                     vmin = fminf(vmin, v);
                 }
@@ -194,7 +235,25 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
                 if (pool_b) pool_b[(int64_t)g * F + gn] = gb * (gb >= 0.0f ? vmax : vmin);
             }
         }
+        if (VST) {
+            // rows of 64 columns (both column tiles of this wavefront) leave as 16 B per lane: one
+            // instruction stores 4 rows x 256 contiguous bytes instead of 2 rows x 128 B
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int colq = (lane & 15) * 4;
+            const int gcol = nt0 * NT + colq;
+            float *gbase = out + ((int64_t)g * T) * ldo + gcol;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = 4 * it + (lane >> 4);
+                const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 64 + (colq ^ (32 * ((row >> 2) & 1)))]);
+                if ((FULLT || row < T) && gcol < F) *reinterpret_cast<float4 *>(gbase + row * ldo) = v4;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
+    GGCN_TRACE(6);
 }
 
 // rowmask from a batched CSR (T <= 32): one thread per node
@@ -211,6 +270,13 @@ __global__ __launch_bounds__(256) void rowmask_kernel(const int32_t *__restrict_
 }
 
 }  // namespace
+
+#ifdef GGCN_LAB_TRACE
+extern "C" int ggcn_lab_trace_read(void *dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ggcn_trace_buf), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask, hipStream_t st)
 {
@@ -248,16 +314,19 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: batch too large");
     const char *wp = static_cast<const char *>(wpack);
     const bool fullt = (T == 32) && (B % (4 * WM) == 0);
-#define GGCN_LAUNCH(SC, AV, KF, FT)                                                                                  \
-    hipLaunchKernelGGL((layer_fused_kernel<SC, AV, KF, FT>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
-                       rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, (int)ldo, pool_a,        \
+    const bool vst = out && (F % 4 == 0) && (ldo % 4 == 0) && aligned16(out);
+#define GGCN_LAUNCH(SC, AV, KF, FT, VS)                                                                                  \
+    hipLaunchKernelGGL((layer_fused_kernel<SC, AV, KF, FT, VS>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
+                       rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, (int)ldo, pool_a,            \
                        pool_b, (int)g_tiles, n_wg, k_steps)
-#define GGCN_PICK(SC)                                            \
-    do {                                                         \
-        if (avec && kfull && fullt) GGCN_LAUNCH(SC, true, true, true);   \
-        else if (avec && kfull) GGCN_LAUNCH(SC, true, true, false);      \
-        else if (avec) GGCN_LAUNCH(SC, true, false, false);              \
-        else GGCN_LAUNCH(SC, false, false, false);                       \
+#define GGCN_PICK(SC)                                                           \
+    do {                                                                        \
+        if (avec && kfull && fullt && vst) GGCN_LAUNCH(SC, true, true, true, true);   \
+        else if (avec && kfull && fullt) GGCN_LAUNCH(SC, true, true, true, false);    \
+        else if (avec && kfull && vst) GGCN_LAUNCH(SC, true, true, false, true);      \
+        else if (avec && kfull) GGCN_LAUNCH(SC, true, true, false, false);            \
+        else if (avec) GGCN_LAUNCH(SC, true, false, false, false);                    \
+        else GGCN_LAUNCH(SC, false, false, false, false);                             \
     } while (0)
     if (precision == GGCN_PREC_F16MX8) GGCN_PICK(1);
     else GGCN_PICK(0);

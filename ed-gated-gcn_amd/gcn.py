@@ -95,9 +95,11 @@ class _GatedLayerFunction(torch.autograd.Function):
             if need[0]:
                 dx = torch.empty(B * T, K, dtype=torch.float32, device=dev)
                 if layer.precision in _capi.PACKED:
+                    # gradients can be far below fp16's range (f16mx8 would flush them): dX always takes
+                    # the bf16x3 linear, which keeps the fp32 exponent range
                     pack_t = layer._packed_weight(lib, st, transposed=True)
                     _capi.check(lib.ggcn_linear(_capi.ptr(dh), F, None, 0, _capi.ptr(pack_t), _capi.ptr(dx), K,
-                                                B * T, F, K, _capi.PREC[layer.precision], st), "ggcn_linear(dX)")
+                                                B * T, F, K, _capi.PREC["bf16x3"], st), "ggcn_linear(dX)")
                 else:
                     wt = weight.detach().t().contiguous()
                     _capi.check(lib.ggcn_linear(_capi.ptr(dh), F, _capi.ptr(wt), K, None, _capi.ptr(dx), K,
@@ -131,7 +133,7 @@ class GraphConvolution(nn.Module):
             self.register_parameter("bias", None)
         # arithmetic of the dense linear: "bf16x3" (3 bf16 MFMAs per product, ~1e-5 abs), "f16mx8" (fp16 MFMA
         # + one block-scaled fp8 correction MFMA, needs |x|,|w| < 65504) or "fp32" (exact fp32 MFMA)
-        self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "bf16x3")
+        self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "f16mx8")
         # one-launch layer (fused_layer.hip) when the batch allows it: T <= 32, binary adjacency, bf16x3
         self.fused = bool(getattr(opt, "ggcn_fused", True)) and os.environ.get("GGCN_FUSED", "1") != "0"
         # dense adjacency handed to forward(): None = let the device detect edge weights (one 4-byte
@@ -149,7 +151,8 @@ class GraphConvolution(nn.Module):
     def _packed_weight(self, lib, stream, transposed=False):
         """MFMA-order image of W (forward) or W^T (backward's dX), rebuilt when W or the precision changes."""
         w = self.weight
-        prec = _capi.PREC[self.precision if self.precision in _capi.PACKED else "bf16x3"]
+        # the transposed image only serves the backward's dX linear, which is always bf16x3
+        prec = _capi.PREC[self.precision if (self.precision in _capi.PACKED and not transposed) else "bf16x3"]
         key = (w.data_ptr(), w._version, w.device, prec)
         slot = 1 if transposed else 0
         if self._pack is None:

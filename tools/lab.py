@@ -80,6 +80,14 @@ def time_variants(what, names):
         elif what == "aggregate":
             rc = lib.ggcn_aggregate(p(x), H, p(csr.rowptr), p(csr.colidx), None, p(b), B, T, H, None, p(g1), p(g2),
                                     p(out), H, p(pa), p(pb), st)
+        elif what == "fused_noout":   # pooled outputs only: no [N,F] store at all
+            rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
+                                      None, H, p(pa), p(pb), prec, st)
+        elif what == "fused2":        # the block's two layers back to back: layer 2 reads what layer 1 wrote
+            rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
+                                      p(out), H, p(pa), p(pb), prec, st)
+            rc = rc or lib.ggcn_layer_fused(p(out), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, p(g2), p(g2), None,
+                                            p(y), H, p(pa), None, prec, st)
         elif what == "fused":
             rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
                                       p(out), H, p(pa), p(pb), prec, st)
