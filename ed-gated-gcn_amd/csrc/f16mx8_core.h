@@ -25,8 +25,9 @@
 // needs |x| < 65504: this mode is for activations of ordinary magnitude (LSTM / GCN outputs);
 // bf16x3 keeps the full fp32 range.
 //
-// LDS per stage and buffer: plane 0 = xh as fp16 [128 rows][64 B], plane 1 = [xl8 (32 B) | xh8 (32 B)]
-// per row -- 128 B per row like bf16x3, same XOR chunk swizzle, same conflict-free reads.
+// LDS per stage and buffer: plane 0 = xh as fp16 [128 rows][64 B], plane 1 = per 4 k the 8 bytes
+// {xl8 x4, xh8 x4} -- 128 B per row like bf16x3, same XOR chunk swizzle, same conflict-free reads
+// (the MX operand's dword order is restored for free when the two 16-byte reads are assembled).
 // Packed weight per (32-column tile, 32-deep stage): [f16 frag k-step 0: 1 KiB][k-step 1: 1 KiB]
 // [MX operand: 64 lanes x 32 B][scales: 64 lanes x 4 B] = 4352 B.
 #pragma once
@@ -90,8 +91,11 @@ __device__ __forceinline__ void set_cvt_saturate(bool on) { __builtin_amdgcn_s_s
 template <typename AT, bool AVEC, bool KFULL, bool ZROWS>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int stages_packed, int wm,
-                                         int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN])
+                                         int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN], int rot = 0)
 {
+    // rot: the K loop starts at stage `rot` and wraps around (same sum, another order).  The column
+    // tiles of one row block run side by side on one XCD and read the same rows of X: started one
+    // stage apart they find each other's lines in L2 instead of missing on them at the same moment.
     using G = Geom<AT>;
     constexpr int EPT = G::EPT, NP = G::NP, NQ = EPT / 4;
     static_assert(BK == 32 && NP <= 4 && RN == 2, "the slot schedule below is written for BK = 32, <= 4 passes, RN = 2");
@@ -121,7 +125,8 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         }
     };
     // pass i of the stage that starts at k0: registers -> split -> LDS buffer `buf`
-    // (plane 0: fp16 xh; plane 1: [xl8 k 0-15 | xl8 k 16-31 | xh8 k 0-15 | xh8 k 16-31])
+    // (plane 0: fp16 xh, 2 B per k; plane 1: per 4 k one {xl8 x4, xh8 x4} group of 8 B, so both planes
+    //  take the same 8-byte write per lane and the same swizzled 16-byte fragment reads)
     Split4 sp[NQ];
     auto split_pass = [&](int i, int k0) {
         const int gk = k0 + s_k;
@@ -149,8 +154,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         for (int q = 0; q < NQ; ++q) {
             const int kq = s_k + 4 * q;  // k offset inside the 32-deep stage
             *reinterpret_cast<uint2 *>(h_plane + a_lds_off(row, kq >> 3) + (kq & 4) * 2) = make_uint2(sp[q].h01, sp[q].h23);
-            *reinterpret_cast<int *>(q_plane + a_lds_off(row, kq >> 4) + (kq & 15)) = sp[q].l8;
-            *reinterpret_cast<int *>(q_plane + a_lds_off(row, 2 + (kq >> 4)) + (kq & 15)) = sp[q].h8;
+            *reinterpret_cast<uint2 *>(q_plane + a_lds_off(row, kq >> 3) + (kq & 4) * 2) = make_uint2((uint32_t)sp[q].l8, (uint32_t)sp[q].h8);
         }
     };
 
@@ -200,9 +204,10 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     auto read_q = [&](int buf, int i, i32x8 &a) {
         const char *q_plane = lds + buf * (2 * BM * ROWB) + BM * ROWB;
         const int row = f_row + i * 32;
-        const i32x4 lo = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, f_half));      // xl8, k = 16h..
-        const i32x4 hi = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, 2 + f_half));  // xh8, k = 16h..
-        a = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        // k = 16h .. 16h+15 as {xl8 x4, xh8 x4} groups: even dwords -> block 0 (xl), odd dwords -> block 1 (xh)
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, 2 * f_half));
+        const i32x4 hi = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, 2 * f_half + 1));
+        a = i32x8{lo[0], lo[2], hi[0], hi[2], lo[1], lo[3], hi[1], hi[3]};
     };
 
 #pragma unroll
@@ -220,18 +225,23 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 #else
     const int stages = (K + BK - 1) / BK;
 #endif
-    const int last_k0 = (stages - 1) * BK;
 
+    // n-th stage of this workgroup's loop -> stage of the K axis (n past the end repeats the last one)
+    auto kstage = [&](int n) {
+        n = n < stages ? n : stages - 1;
+        const int s = n + rot;
+        return s >= stages ? s - stages : s;
+    };
 #pragma unroll
-    for (int p = 0; p < NP; ++p) load_a_pass(p, 0);
-    load_bf(0, b0, b1);
+    for (int p = 0; p < NP; ++p) load_a_pass(p, kstage(0) * BK);
+    load_bf(kstage(0), b0, b1);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        split_pass(p, 0);
+        split_pass(p, kstage(0) * BK);
         write_pass(0, p);
     }
 #pragma unroll
-    for (int p = 0; p < NP; ++p) load_a_pass(p, BK < last_k0 ? BK : last_k0);
+    for (int p = 0; p < NP; ++p) load_a_pass(p, kstage(1) * BK);
     __syncthreads();
 
     // One stage = 8 slots of 128 matrix-pipe cycles each; the source order below IS the issue order
@@ -244,13 +254,12 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     // The MX operand of B is loaded at the top of its stage (used from slot 4 on).
     auto stage = [&](int st, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        const int k_next1 = (st + 1) * BK < last_k0 ? (st + 1) * BK : last_k0;
-        const int k_next2 = (st + 2) * BK;
-        const int ka = k_next2 < last_k0 ? k_next2 : last_k0;
+        const int k_next1 = kstage(st + 1) * BK;
+        const int ka = kstage(st + 2) * BK;
         f16x8 ah[2][2];
         i32x8 aq[2];
         read_h(buf, 0, ah[0]);
-        load_bq(st, bq, sq);
+        load_bq(kstage(st), bq, sq);
         GGCN_SB();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -278,7 +287,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             GGCN_SB();
             acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bq[0], acc[i][0], 0, 0, 0, scale_a, 0, sq[0]);
             GGCN_SB();
-            if (i == 0) load_bf(st + 1, b0, b1);  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
+            if (i == 0) load_bf(kstage(st + 1), b0, b1);  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
             GGCN_SB();
             acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bq[1], acc[i][1], 0, 0, 0, scale_a, 0, sq[1]);
             GGCN_SB();

@@ -70,6 +70,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
 #endif
     int g_tile, n_wgi;
     if (!tile_of_block(blockIdx.x, g_tiles, n_wg, g_tile, n_wgi)) return;
+#ifdef GGCN_LAB_ONLY_N0  // probe: only the first column tile of every row block runs (how much of X is fetched once?)
+    if (n_wgi != 0) return;
+#endif
 #ifdef GGCN_LAB_REVERSE2  // probe: the layer that applies a store gate (layer 2) walks the row blocks backwards
     if (store_gate) g_tile = g_tiles - 1 - g_tile;
 #endif
@@ -137,7 +140,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
     if constexpr (SCH == 0)
         bx3::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K_loop, k_steps, wm, nt0, n_tiles_total, lds, acc);
     else
+#ifdef GGCN_MX_LAB_ROT
+        mx8::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K_loop, k_steps / 2, wm, nt0, n_tiles_total, lds, acc,
+                                                  (n_wgi * GGCN_MX_LAB_ROT) % ((K_loop + BK - 1) / BK));
+#else
         mx8::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K_loop, k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
+#endif
 
     GGCN_TRACE(5);
     const int c = lane & 31, h = lane >> 5;

@@ -88,3 +88,21 @@ for i in sorted(cus[key], key=lambda i: start[i]):
 hist, edges = np.histogram(le, bins=40, range=(0, end.max()))
 print("histogram of main-loop-end times (40 bins over the kernel):")
 print(" ".join("%d" % h for h in hist))
+# siblings = the 3 column tiles of one row block (tile_of_block: xcd = id & 7, slot = id >> 3)
+n_wg = 3
+ids = tr[:, 0].astype(np.int64)
+m_tile = (ids >> 3) // n_wg * 8 + (ids & 7)
+same_xcc = 0; spread = []; xcc_of_id_ok = 0
+by_tile = collections.defaultdict(list)
+for i in range(n):
+    by_tile[int(m_tile[i])].append(i)
+    xcc_of_id_ok += int(xcc[i] == (ids[i] & 7))
+for t, members in by_tile.items():
+    if len(members) == n_wg:
+        same_xcc += int(len({int(xcc[i]) for i in members}) == 1)
+        spread.append(max(start[i] for i in members) - min(start[i] for i in members))
+print("XCC_ID == id & 7 for %d of %d blocks" % (xcc_of_id_ok, n))
+print("row blocks whose 3 column tiles ran on one XCD: %d of %d" % (same_xcc, len(by_tile)))
+print("start-time spread inside a sibling group: median %.2f us  p90 %.2f  max %.2f" % (np.median(spread), np.percentile(spread, 90), max(spread)))
+spread_le = [max(le[i] for i in m) - min(le[i] for i in m) for m in by_tile.values() if len(m) == n_wg]
+print("loop-end spread inside a sibling group:   median %.2f us  p90 %.2f  max %.2f" % (np.median(spread_le), np.percentile(spread_le, 90), max(spread_le)))
