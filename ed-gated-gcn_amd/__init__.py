@@ -10,6 +10,7 @@ Public surface (mirrors the reference interface for this path):
 * ``gated_gcn_block``   -- ``models/bert_amir5.py:621-640``: gate -> gc1 -> gate ->
   gc2 -> gate -> max-pool, never materialising the [B,T,H] gates.
 * ``BatchedCSR``        -- many sentence graphs as one block-diagonal CSR.
+* ``subword_pool``      -- ``models/bert_amir5.py:600``: ``bmm(transform, x)`` on the non-zeros only.
 
 All compute is in ``libggcn_hip.so`` (hand-written HIP for gfx950, C ABI in
 ``include/ggcn.h``).  There is no CPU or PyTorch fallback: without the library or
@@ -19,7 +20,8 @@ from ._capi import lib_path, load_library  # noqa: F401
 from .csr import BatchedCSR  # noqa: F401
 from .gcn import GraphConvolution  # noqa: F401
 from .gated_block import gated_gcn_block  # noqa: F401
+from .pooling import subword_pool  # noqa: F401
 from .classifier import GatedGCNEventDetector, LegacyBertAdapter  # noqa: F401
 
-__all__ = ["GraphConvolution", "gated_gcn_block", "BatchedCSR", "GatedGCNEventDetector", "LegacyBertAdapter",
+__all__ = ["GraphConvolution", "gated_gcn_block", "BatchedCSR", "subword_pool", "GatedGCNEventDetector", "LegacyBertAdapter",
            "load_library", "lib_path"]

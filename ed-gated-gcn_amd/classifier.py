@@ -5,13 +5,15 @@ Sub-module names, shapes and construction order follow the reference, so a refer
 ``state_dict`` loads unchanged (``bert.*``, ``dense``, ``lstm``, ``gc1``, ``gc2``, ``gate1``,
 ``gate2``, ``fc``) and ``Instructor._reset_params`` (``train.py:75-84``) initialises it the same
 way.  ``forward(inputs) -> (logits, gate_reg, kl_reg, scores)`` like every live model of
-``train.py:109``.  BERT, the BiLSTM and the small heads stay PyTorch-ROCm.
+``train.py:109``.  The sub-word pooling (``:600``) and the block (``:621-640``) run on the HIP path;
+BERT, the BiLSTM and the small heads stay PyTorch-ROCm.
 """
 import torch
 import torch.nn as nn
 
 from .gated_block import gated_gcn_block
 from .gcn import GraphConvolution
+from .pooling import subword_pool
 
 
 class LegacyBertAdapter(nn.Module):
@@ -62,7 +64,7 @@ class GatedGCNEventDetector(nn.Module):
             adj = adj[:, :T, :T]
         x, pooled = self.bert(ids, seg, output_all_encoded_layers=True)     # :591
         x = torch.cat(x[-self.n_layer:], dim=-1)                            # :596
-        x = torch.bmm(transform, x)                                         # :600
+        x = subword_pool(transform.float(), x)                              # :600 on the HIP path (non-zeros only)
         rows = torch.arange(B, device=x.device)
         anchor_rep = self.dropout(x[rows, anchor])                          # :604-608: the anchor token's row
         x, _ = self.lstm(x)                                                 # :610

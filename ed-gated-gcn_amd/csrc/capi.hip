@@ -152,6 +152,13 @@ int ggcn_dweight(const float *X, int64_t ldx, const float *dH, int64_t ldg, int6
     return dweight(X, ldx, dH, ldg, n_rows, K, F, dW, lddw, workspace, as_stream(stream));
 }
 
+int ggcn_subword_pool(const float *A, int64_t sa_b, int64_t sa_r, int64_t sa_c, const float *X, int64_t x_batch,
+                      int64_t ldx, float *Y, int64_t y_batch, int64_t ldy, int B, int R, int C, int D,
+                      ggcn_stream_t stream)
+{
+    return subword_pool(A, sa_b, sa_r, sa_c, X, x_batch, ldx, Y, y_batch, ldy, B, R, C, D, as_stream(stream));
+}
+
 size_t ggcn_overlap_workspace_bytes(int B) { return overlap_workspace_bytes(B); }
 
 int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,

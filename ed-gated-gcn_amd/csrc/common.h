@@ -57,6 +57,8 @@ int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t
               const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
               float *pool_a, float *pool_b, hipStream_t st);
 
+int subword_pool(const float *A, int64_t sa_b, int64_t sa_r, int64_t sa_c, const float *X, int64_t x_batch,
+                 int64_t ldx, float *Y, int64_t y_batch, int64_t ldy, int B, int R, int C, int D, hipStream_t st);
 int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask, hipStream_t st);
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const float *bias,
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,

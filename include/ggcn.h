@@ -206,6 +206,19 @@ size_t ggcn_overlap_workspace_bytes(int B);
 int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy,
                       void *workspace, ggcn_stream_t stream);
 
+/* ---- sub-word -> word pooling (the step before the path) ---------------
+ * Replaces models/bert_amir5.py:600 `x = torch.bmm(transform, x)`:
+ *   Y[b,r,:] = sum_c A[b,r,c] * X[b,c,:]
+ * A [B,R,C] float32 with ELEMENT strides (the reference passes the non-contiguous slice
+ * inputs['transform'][:, :T, :L]; data_utils.py:749-766 puts 1/l on the l sub-word positions of
+ * word r), C <= 2048.  X [B,C,D] and Y [B,R,D] float32: row c of batch b starts at
+ * X + b*x_batch + c*ldx (elements), likewise Y.  Only the non-zeros of A are multiplied, in
+ * ascending c.  The backward dX = A^T . dY is the same call with sa_r / sa_c and R / C swapped. */
+int ggcn_subword_pool(const float *A, int64_t sa_b, int64_t sa_r, int64_t sa_c,
+                      const float *X, int64_t x_batch, int64_t ldx,
+                      float *Y, int64_t y_batch, int64_t ldy,
+                      int B, int R, int C, int D, ggcn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

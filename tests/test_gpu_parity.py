@@ -577,3 +577,61 @@ def test_hipgraph_capture_replays_bit_identically(pkg, dev):
     torch.cuda.synchronize()
     for k in ("gcn1", "x", "out", "x1", "y1", "xy"):
         assert torch.equal(ref[k], got[k]), k
+
+
+# ---------------------------------------------------------------- sub-word pooling
+def _transform_like_reference(B, T, L, rng, ori_ml=None, bert_ml=None):
+    """data_utils.py:749-766: word i covers l_i consecutive sub-word positions starting at offset 1
+    ([CLS] first), each with weight 1/l_i; padded to [ORI_ML, BERT_ML]."""
+    ori_ml, bert_ml = ori_ml or T, bert_ml or L
+    tr = np.zeros((B, ori_ml, bert_ml), dtype=np.float32)
+    for b in range(B):
+        n_words = int(rng.integers(1, T + 1))
+        off = 1
+        for i in range(n_words):
+            l = int(rng.integers(1, 5))
+            if off + l >= L:
+                break
+            tr[b, i, off:off + l] = 1.0 / l
+            off += l
+    return tr
+
+
+@pytest.mark.parametrize("B,T,L,D,pad", [(4, 31, 60, 9216, True), (3, 7, 300, 1000, False), (2, 5, 9, 37, True),
+                                         (1, 1, 1, 4, False)])
+def test_subword_pool_matches_bmm(pkg, dev, B, T, L, D, pad):
+    """bert_amir5.py:600 on the non-zeros only == the dense bmm (same products; the order of a row's
+    few additions may differ from the BLAS kernel's -> 1e-6 relative)."""
+    rng = np.random.default_rng(B * 1000 + L)
+    full = _transform_like_reference(B, T, L, rng, T + 3 if pad else None, L + 5 if pad else None)
+    x = rng.standard_normal((B, L, D)).astype(np.float32)
+    tr_full = torch.from_numpy(full).to(dev)
+    tr = tr_full[:, :T, :L]                       # the reference's non-contiguous slice (:585)
+    ref = torch.bmm(torch.from_numpy(full[:, :T, :L].copy()), torch.from_numpy(x))
+    got = pkg.subword_pool(tr, torch.from_numpy(x).to(dev))
+    assert got.shape == (B, T, D)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_subword_pool_dense_rows_and_backward(pkg, dev):
+    """A transform with arbitrary (also negative) entries and empty rows; the backward is the transposed
+    product and matches autograd through torch.bmm."""
+    rng = np.random.default_rng(5)
+    B, T, L, D = 3, 6, 20, 520
+    a = (rng.standard_normal((B, T, L)) * (rng.random((B, T, L)) < 0.3)).astype(np.float32)
+    a[1, 2, :] = 0.0
+    x = rng.standard_normal((B, L, D)).astype(np.float32)
+    dy = rng.standard_normal((B, T, D)).astype(np.float32)
+    xr = torch.from_numpy(x).requires_grad_(True)
+    ref = torch.bmm(torch.from_numpy(a), xr)
+    ref.backward(torch.from_numpy(dy))
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+    got = pkg.subword_pool(torch.from_numpy(a).to(dev), xg)
+    got.backward(torch.from_numpy(dy).to(dev))
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)
+    assert float(got.detach()[1, 2].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        pkg.subword_pool(torch.from_numpy(a), torch.from_numpy(x))          # no CPU path
+    with pytest.raises(RuntimeError):
+        pkg.subword_pool(torch.from_numpy(a).to(dev), torch.from_numpy(x).to(dev)[:, :5])  # shape mismatch
