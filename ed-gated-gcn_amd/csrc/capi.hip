@@ -58,10 +58,11 @@ int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
 int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask,
                      const float *bias, int B, int T, int K, int F, const float *store_gate,
                      const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
-                     float *pool_a, float *pool_b, int precision, ggcn_stream_t stream)
+                     float *pool_a, float *pool_b, float *overlap_partial, const float *overlap_in,
+                     float *overlap_out, int precision, ggcn_stream_t stream)
 {
     return layer_fused(X, ldx, wpack, rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out,
-                       ldo, pool_a, pool_b, precision, as_stream(stream));
+                       ldo, pool_a, pool_b, overlap_partial, overlap_in, overlap_out, precision, as_stream(stream));
 }
 
 size_t ggcn_weight_pack_bytes(int K, int F, int precision) { return weight_pack_bytes(K, F, precision); }

@@ -62,8 +62,8 @@ int subword_pool(const float *A, int64_t sa_b, int64_t sa_r, int64_t sa_c, const
 int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask, hipStream_t st);
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const float *bias,
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
-                const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b, int precision,
-                hipStream_t st);
+                const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,
+                float *overlap_partial, const float *overlap_in, float *overlap_out, int precision, hipStream_t st);
 
 int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                        const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,

@@ -61,15 +61,36 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
     const uint32_t *__restrict__ rowmask, const float *__restrict__ bias, int B, int T, int K, int F,
     const float *__restrict__ store_gate, const float *__restrict__ pool_gate_a,
     const float *__restrict__ pool_gate_b, float *__restrict__ out, int ldo,
-    float *__restrict__ pool_a, float *__restrict__ pool_b, int g_tiles, int n_wg, int k_steps)
+    float *__restrict__ pool_a, float *__restrict__ pool_b, float *__restrict__ ov_partial,
+    const float *__restrict__ ov_in, float *__restrict__ ov_out, int g_tiles, int n_wg, int k_steps)
 {
 #if defined(GGCN_LAB_LDS_PAD)
     __shared__ __attribute__((aligned(16))) char lds[kLdsBytes + GGCN_LAB_LDS_PAD];  // occupancy experiment
 #else
     __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
 #endif
+    // bert_amir5.py:638 for the launch BEFORE this one on the stream: block 0 adds the per-(graph,
+    // 64-column group) partial dot products that launch left in ov_in, in a fixed order
+    if (ov_in && blockIdx.x == 0) {
+        float *red = reinterpret_cast<float *>(lds);
+        const int n_part = B * ((F + 63) / 64);
+        float sdot = 0.0f;
+        for (int idx = threadIdx.x; idx < n_part; idx += kThreads) sdot += ov_in[idx];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sdot += __shfl_xor(sdot, d);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sdot;
+        __syncthreads();
+        if (threadIdx.x == 0) *ov_out = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
+        __syncthreads();
+    }
+#ifdef GGCN_PERSIST  // probe: GGCN_PERSIST resident workgroups walk the tile list with stride gridDim.x
+    for (int vid = blockIdx.x;; vid += gridDim.x) {
+#else
+    {
+        const int vid = blockIdx.x;
+#endif
     int g_tile, n_wgi;
-    if (!tile_of_block(blockIdx.x, g_tiles, n_wg, g_tile, n_wgi)) return;
+    if (!tile_of_block(vid, g_tiles, n_wg, g_tile, n_wgi)) return;
 #ifdef GGCN_LAB_ONLY_N0  // probe: only the first column tile of every row block runs (how much of X is fetched once?)
     if (n_wgi != 0) return;
 #endif
@@ -198,6 +219,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
             rinv[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_base + 4 * row0, __float_as_int(inv)));
         }
 
+        float dot = 0.0f;  // this wavefront's share of sum_f x1[g,f] * y1[g,f] (bert_amir5.py:638)
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             if (nt0 + j >= n_tiles_total) break;  // wavefront-uniform: column tile past F
@@ -239,9 +261,16 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
             vmin = fminf(vmin, __shfl_xor(vmin, 32));
             if (h == 0 && col_ok[j]) {
                 const float ga = vga[i][j], gb = vgb[i][j];
-                if (pool_a) pool_a[(int64_t)g * F + gn] = ga * (ga >= 0.0f ? vmax : vmin);
-                if (pool_b) pool_b[(int64_t)g * F + gn] = gb * (gb >= 0.0f ? vmax : vmin);
+                const float pa = ga * (ga >= 0.0f ? vmax : vmin), pb = gb * (gb >= 0.0f ? vmax : vmin);
+                if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
+                if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
+                dot = fmaf(pa, pb, dot);
             }
+        }
+        if (ov_partial && nt0 < n_tiles_total) {  // fixed butterfly order; lanes with h = 1 hold 0
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
+            if (lane == 0) ov_partial[(int64_t)g * ((F + 63) / 64) + (nt0 >> 1)] = dot;
         }
         if (VST) {
             // rows of 64 columns (both column tiles of this wavefront) leave as 16 B per lane: one
@@ -262,6 +291,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
         }
     }
     GGCN_TRACE(6);
+#ifdef GGCN_PERSIST
+    __syncthreads();  // the next tile's prologue overwrites the LDS the epilogue staged its rows in
+#endif
+    }
 }
 
 // rowmask from a batched CSR (T <= 32): one thread per node
@@ -299,9 +332,11 @@ int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint
 
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const float *bias,
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
-                const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b, int precision,
-                hipStream_t st)
+                const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,
+                float *overlap_partial, const float *overlap_in, float *overlap_out, int precision, hipStream_t st)
 {
+    if ((overlap_in == nullptr) != (overlap_out == nullptr))
+        return fail(GGCN_EINVAL, "ggcn_layer_fused: overlap_in and overlap_out go together");
     if (precision != GGCN_PREC_BF16X3 && precision != GGCN_PREC_F16MX8)
         return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: precision %d (use bf16x3 or f16mx8)", precision);
     if (!X || !wpack || !rowmask) return fail(GGCN_EINVAL, "ggcn_layer_fused: null input pointer");
@@ -318,7 +353,10 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
     const int k_steps = round_up(K, BK) / KSTEP;
     const int64_t g_tiles = ((int64_t)B + 4 * WM - 1) / (4 * WM);
     const int n_wg = (F + BN - 1) / BN;
-    const int64_t grid = grid_for(g_tiles, n_wg);
+    int64_t grid = grid_for(g_tiles, n_wg);
+#ifdef GGCN_PERSIST
+    if (grid > GGCN_PERSIST) grid = GGCN_PERSIST;
+#endif
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: batch too large");
     const char *wp = static_cast<const char *>(wpack);
     const bool fullt = (T == 32) && (B % (4 * WM) == 0);
@@ -326,7 +364,7 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
 #define GGCN_LAUNCH(SC, AV, KF, FT, VS)                                                                                  \
     hipLaunchKernelGGL((layer_fused_kernel<SC, AV, KF, FT, VS>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
                        rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, (int)ldo, pool_a,            \
-                       pool_b, (int)g_tiles, n_wg, k_steps)
+                       pool_b, overlap_partial, overlap_in, overlap_out, (int)g_tiles, n_wg, k_steps)
 #define GGCN_PICK(SC)                                                           \
     do {                                                                        \
         if (avec && kfull && fullt && vst) GGCN_LAUNCH(SC, true, true, true, true);   \

@@ -39,6 +39,19 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2):
     ``gcn1`` (ungated, feeds layer 2), ``x1``, ``y1``, ``xy``, ``x`` (gated layer-2 output), ``out``.
     """
     csr = adj if isinstance(adj, BatchedCSR) else gc1._as_csr(adj, x)
+    training = torch.is_grad_enabled() and (gc1._needs_grad(x, gate1, gate2) or gc2._needs_grad(x, gate2))
+    if (not training and gc1.takes_fused_path(x, csr) and gc2.takes_fused_path(x, csr)
+            and gc1.out_features == gc2.out_features):
+        # two launches in all: layer 1 leaves its share of sum_f x1*y1 per (graph, 64 columns), layer 2's
+        # launch adds them up before it starts on its own tiles (:638 costs no launch of its own)
+        B, F = x.shape[0], gc1.out_features
+        part = torch.empty(B, (F + 63) // 64, dtype=torch.float32, device=x.device)
+        xy = torch.empty((), dtype=torch.float32, device=x.device)
+        gcn1, x1, y1 = gc1.forward_gated(x, csr, store_gate=None, pool_gate_a=gate1, pool_gate_b=gate2,
+                                         want_pool_a=True, want_pool_b=True, overlap_partial=part)   # :626-636
+        x2, out, _ = gc2.forward_gated(gcn1, csr, store_gate=gate2, pool_gate_a=gate2, want_pool_a=True,
+                                       overlap_reduce=(part, xy))                                    # :638-640
+        return {"gcn1": gcn1, "x1": x1, "y1": y1, "xy": xy, "x": x2, "out": out}
     gcn1, x1, y1 = gc1.forward_gated(x, csr, store_gate=None, pool_gate_a=gate1, pool_gate_b=gate2,
                                      want_pool_a=True, want_pool_b=True)           # :626-636
     if torch.is_grad_enabled() and (x1.requires_grad or y1.requires_grad):

@@ -227,13 +227,25 @@ class GraphConvolution(nn.Module):
                                             or (self.bias is not None and self.bias.requires_grad)
                                             or any(g is not None and g.requires_grad for g in gates))
 
+    def takes_fused_path(self, text, csr):
+        """True when ``forward_gated`` will run as ONE launch (``ggcn_layer_fused``): graphs of <= 32
+        nodes, 0/1 adjacency, float32 features, a split-precision linear."""
+        return (self.fused and self.precision in _capi.PACKED and csr.rowmask is not None and csr.is_binary
+                and text.dtype == torch.float32)
+
     def forward_gated(self, text, adj, store_gate=None, pool_gate_a=None, pool_gate_b=None,
-                      want_out=True, want_pool_a=False, want_pool_b=False, _internal=False):
+                      want_out=True, want_pool_a=False, want_pool_b=False, _internal=False,
+                      overlap_partial=None, overlap_reduce=None):
         """Layer + gate + max-pool in one aggregation pass.
 
         Returns ``(out [B,T,F] or None, pool_a [B,F] or None, pool_b [B,F] or None)`` with
         ``out = y * store_gate`` and ``pool_x = max_t (y * pool_gate_x)``, ``y`` being the
-        plain layer output.  Gates are ``[B,F]`` (broadcast over tokens)."""
+        plain layer output.  Gates are ``[B,F]`` (broadcast over tokens).
+
+        One-launch path only (``takes_fused_path``): ``overlap_partial`` (float32 ``[B, ceil(F/64)]``)
+        receives this layer's share of ``sum_f pool_a*pool_b``; ``overlap_reduce=(partials, xy)`` makes
+        this launch reduce the partials an earlier launch wrote into the scalar ``xy``
+        (``bert_amir5.py:638`` without its own launches)."""
         self._check(text)
         csr = self._as_csr(adj, text)
         if not _internal and self._needs_grad(text, store_gate, pool_gate_a, pool_gate_b):
@@ -257,8 +269,9 @@ class GraphConvolution(nn.Module):
                     raise RuntimeError("%s must be a contiguous [B,F]=[%d,%d] tensor, got %s"
                                        % (name, B, F, tuple(g.shape)))
         half = text.dtype == torch.float16
-        use_fused = (self.fused and self.precision in _capi.PACKED and csr.rowmask is not None
-                     and csr.is_binary and not half)
+        use_fused = self.takes_fused_path(text, csr)
+        if (overlap_partial is not None or overlap_reduce is not None) and not use_fused:
+            raise RuntimeError("overlap_partial / overlap_reduce need the one-launch layer (takes_fused_path)")
         hidden = None if use_fused else self.linear(x2d)
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
@@ -272,7 +285,10 @@ class GraphConvolution(nn.Module):
                                                  _capi.ptr(csr.rowmask), _capi.ptr(bias), B, T,
                                                  self.in_features, F, _capi.ptr(store_gate),
                                                  _capi.ptr(pool_gate_a), _capi.ptr(pool_gate_b), _capi.ptr(out),
-                                                 F, _capi.ptr(pa), _capi.ptr(pb), _capi.PREC[self.precision], st),
+                                                 F, _capi.ptr(pa), _capi.ptr(pb), _capi.ptr(overlap_partial),
+                                                 _capi.ptr(overlap_reduce[0]) if overlap_reduce else None,
+                                                 _capi.ptr(overlap_reduce[1]) if overlap_reduce else None,
+                                                 _capi.PREC[self.precision], st),
                             "ggcn_layer_fused")
                 return (None if out is None else out.view(B, T, F)), pa, pb
             agg = lib.ggcn_aggregate_h if half else lib.ggcn_aggregate

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 2
+#define GGCN_ABI_VERSION 3
 
 typedef void *ggcn_stream_t;
 
@@ -191,11 +191,17 @@ int ggcn_aggregate_h(const void *Hd, int64_t ldh,
  * the graph's 0/1 adjacency with a second MFMA, then divided, biased, gated, pooled and
  * stored.  Same outputs and argument meaning as ggcn_linear(GGCN_PREC_BF16X3) followed by
  * ggcn_aggregate; X is [B*T, K], wpack from ggcn_weight_pack(K, F, precision), rowmask
- * uint32[B*T]; precision is GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8. */
+ * uint32[B*T]; precision is GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8.
+ * The gate-diversity regulariser (models/bert_amir5.py:638) can ride along instead of taking
+ * ggcn_gate_overlap's two launches: overlap_partial (NULL or float[B * ceil(F/64)]) receives, per graph
+ * and 64-column group, sum_f pool_a[g,f]*pool_b[g,f] of THIS launch (layer 1: x1.y1); overlap_in /
+ * overlap_out (both or neither) make this launch first reduce the partials an EARLIER launch on the
+ * same stream wrote (same B, F) to *overlap_out = mean_b sum_f, in a fixed order (deterministic). */
 int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask,
                      const float *bias, int B, int T, int K, int F,
                      const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
                      float *out, int64_t ldo, float *pool_a, float *pool_b,
+                     float *overlap_partial, const float *overlap_in, float *overlap_out,
                      int precision, ggcn_stream_t stream);
 
 /* ---- gate-diversity regulariser --------------------------------------------

@@ -635,3 +635,29 @@ def test_subword_pool_dense_rows_and_backward(pkg, dev):
         pkg.subword_pool(torch.from_numpy(a), torch.from_numpy(x))          # no CPU path
     with pytest.raises(RuntimeError):
         pkg.subword_pool(torch.from_numpy(a).to(dev), torch.from_numpy(x).to(dev)[:, :5])  # shape mismatch
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
+@pytest.mark.parametrize("B,T,H", [(5, 7, 96), (9, 32, 72), (130, 31, 256), (3, 1, 8)])
+def test_regulariser_folded_into_the_layer_launches(pkg, dev, B, T, H, precision):
+    """bert_amir5.py:638 without launches of its own (partials from layer 1's epilogue, reduced by layer
+    2's launch) == ggcn_gate_overlap on the same x1, y1 == the oracle; and it is deterministic."""
+    from ed_gated_gcn_amd import synth
+    from ed_gated_gcn_amd.gated_block import gate_overlap
+    rng = np.random.default_rng(B + H)
+    adj = torch.from_numpy(synth.dependency_batch(B, T, min(3.0, T), seed=4, lengths=rng.integers(1, T + 1, size=B)))
+    x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32))
+    g1 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32)))
+    g2 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32)))
+    (w1, b1), (w2, b2) = synth.layer_params(H, H, seed=1), synth.layer_params(H, H, seed=2)
+    l1, l2 = _layer(pkg, dev, w1, b1, precision), _layer(pkg, dev, w2, b2, precision)
+    with torch.no_grad():
+        r = pkg.gated_gcn_block(x.to(dev), adj.to(dev), g1.to(dev), g2.to(dev), l1, l2)
+        again = pkg.gated_gcn_block(x.to(dev), adj.to(dev), g1.to(dev), g2.to(dev), l1, l2)
+        standalone = gate_overlap(r["x1"], r["y1"])
+    ref = ref_dense.gated_block(x, adj.float(), g1, g2, torch.from_numpy(w1), torch.from_numpy(b1),
+                                torch.from_numpy(w2), torch.from_numpy(b2))
+    assert float(r["xy"]) == float(again["xy"])
+    scale = max(1.0, abs(float(ref["xy"])))
+    assert abs(float(r["xy"]) - float(standalone)) <= 2e-6 * scale      # same products, another summation tree
+    assert abs(float(r["xy"]) - float(ref["xy"])) <= 1e-4 * scale

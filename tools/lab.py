@@ -82,15 +82,15 @@ def time_variants(what, names):
                                     p(out), H, p(pa), p(pb), st)
         elif what == "fused_noout":   # pooled outputs only: no [N,F] store at all
             rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
-                                      None, H, p(pa), p(pb), prec, st)
+                                      None, H, p(pa), p(pb), None, None, None, prec, st)
         elif what == "fused2":        # the block's two layers back to back: layer 2 reads what layer 1 wrote
             rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
-                                      p(out), H, p(pa), p(pb), prec, st)
+                                      p(out), H, p(pa), p(pb), None, None, None, prec, st)
             rc = rc or lib.ggcn_layer_fused(p(out), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, p(g2), p(g2), None,
-                                            p(y), H, p(pa), None, prec, st)
+                                            p(y), H, p(pa), None, None, None, None, prec, st)
         elif what == "fused":
             rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
-                                      p(out), H, p(pa), p(pb), prec, st)
+                                      p(out), H, p(pa), p(pb), None, None, None, prec, st)
         else:
             raise SystemExit("unknown target " + what)
         assert rc == 0, lib.ggcn_last_error()

@@ -32,7 +32,7 @@ pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H, prec), dtype=torch.uint8, de
 assert lib.ggcn_weight_pack(p(w), H, H, H, prec, 0, p(pack), None) == 0
 def run():
     rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2), None if NOOUT else p(out), H,
-                              p(pa), p(pb), prec, None)
+                              p(pa), p(pb), None, None, None, prec, None)
     assert rc == 0
 for _ in range(5):
     run()
