@@ -111,12 +111,6 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         k0 = 0;
 #endif
         const int gk = k0 + s_k;
-#ifdef GGCN_MX_LAB_TILED  // timing probe: X addressed as [row block][stage][128 rows][32 k] -> one contiguous 16 KiB per stage
-        if constexpr (AVEC) {
-            load16<AT>(arow[i] + (k0 / 32) * 4096 + s_k, ra[i]);
-            return;
-        }
-#endif
         if constexpr (AVEC) {
             load16<AT>(arow[i] + ((KFULL || gk < K) ? gk : 0), ra[i]);
         } else {

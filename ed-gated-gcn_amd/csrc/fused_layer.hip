@@ -83,19 +83,11 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
         if (threadIdx.x == 0) *ov_out = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
         __syncthreads();
     }
-#ifdef GGCN_PERSIST  // probe: GGCN_PERSIST resident workgroups walk the tile list with stride gridDim.x
-    for (int vid = blockIdx.x;; vid += gridDim.x) {
-#else
-    {
-        const int vid = blockIdx.x;
-#endif
+    const int vid = blockIdx.x;
     int g_tile, n_wgi;
     if (!tile_of_block(vid, g_tiles, n_wg, g_tile, n_wgi)) return;
 #ifdef GGCN_LAB_ONLY_N0  // probe: only the first column tile of every row block runs (how much of X is fetched once?)
     if (n_wgi != 0) return;
-#endif
-#ifdef GGCN_LAB_REVERSE2  // probe: the layer that applies a store gate (layer 2) walks the row blocks backwards
-    if (store_gate) g_tile = g_tiles - 1 - g_tile;
 #endif
 #ifdef GGCN_LAB_TRACE
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
@@ -104,15 +96,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
         ggcn_trace_buf[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // HW_REG_XCC_ID
     }
     GGCN_TRACE(3);
-#endif
-#if defined(GGCN_STAGGER)
-    // Two workgroups share a CU and run the same program; started together they stay in lockstep
-    // and reach their (MFMA-free) epilogues at the same time.  Delay the second resident set of the
-    // initial dispatch by about half a tile once: every later block inherits its slot's phase.
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-#pragma unroll 1
-        for (int i = 0; i < GGCN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
 #endif
 
     const int tid = threadIdx.x;
@@ -135,9 +118,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
         avalid[i] = (g < B) && (FULLT || r < T);
         const int64_t node = avalid[i] ? (int64_t)g * T + r : 0;  // clamped, zeroed by the select
         arow[i] = X + node * ldx;
-#ifdef GGCN_MX_LAB_TILED
-        arow[i] = X + (int64_t)g_tile * 128 * ldx + row * 32;
-#endif
     }
     // this lane's adjacency row (node lane&31) of each of the 4 graphs: in flight under the main loop
     uint32_t mask[4];
@@ -291,10 +271,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
         }
     }
     GGCN_TRACE(6);
-#ifdef GGCN_PERSIST
-    __syncthreads();  // the next tile's prologue overwrites the LDS the epilogue staged its rows in
-#endif
-    }
 }
 
 // rowmask from a batched CSR (T <= 32): one thread per node
@@ -353,10 +329,7 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
     const int k_steps = round_up(K, BK) / KSTEP;
     const int64_t g_tiles = ((int64_t)B + 4 * WM - 1) / (4 * WM);
     const int n_wg = (F + BN - 1) / BN;
-    int64_t grid = grid_for(g_tiles, n_wg);
-#ifdef GGCN_PERSIST
-    if (grid > GGCN_PERSIST) grid = GGCN_PERSIST;
-#endif
+    const int64_t grid = grid_for(g_tiles, n_wg);
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: batch too large");
     const char *wp = static_cast<const char *>(wpack);
     const bool fullt = (T == 32) && (B % (4 * WM) == 0);
