@@ -33,8 +33,8 @@ PROTOTYPES = {
                                c_vp, c_i64, c_vp, c_vp, c_vp]),
     "ggcn_gate_pool_backward": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32,
                                         c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
-    "ggcn_dweight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
-    "ggcn_dweight": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    "ggcn_dweight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32, c_i32]),
+    "ggcn_dweight": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "ggcn_inv_denominators": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "ggcn_aggregate_t": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "ggcn_linear_h": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
@@ -44,7 +44,7 @@ PROTOTYPES = {
     "ggcn_gate_overlap": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2}
 PACKED = ("bf16x3", "f16mx8")  # precisions whose linear reads a ggcn_weight_pack image
 FLAG_WEIGHTED = 1

@@ -145,12 +145,19 @@ int ggcn_gate_pool_backward(const float *out, int64_t ldo, const float *store_ga
                               d_ga, d_gb, as_stream(stream));
 }
 
-size_t ggcn_dweight_workspace_bytes(int64_t n_rows, int K, int F) { return dweight_workspace_bytes(n_rows, K, F); }
+size_t ggcn_dweight_workspace_bytes(int64_t n_rows, int K, int F, int precision)
+{
+    return precision == GGCN_PREC_FP32 ? dweight_workspace_bytes(n_rows, K, F) : dweight_bx3_workspace_bytes(n_rows, K, F);
+}
 
 int ggcn_dweight(const float *X, int64_t ldx, const float *dH, int64_t ldg, int64_t n_rows, int K, int F,
-                 float *dW, int64_t lddw, void *workspace, ggcn_stream_t stream)
+                 float *dW, int64_t lddw, int precision, void *workspace, ggcn_stream_t stream)
 {
-    return dweight(X, ldx, dH, ldg, n_rows, K, F, dW, lddw, workspace, as_stream(stream));
+    if (precision == GGCN_PREC_FP32)
+        return dweight(X, ldx, dH, ldg, n_rows, K, F, dW, lddw, workspace, as_stream(stream));
+    if (precision != GGCN_PREC_BF16X3)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_dweight: precision %d (gradients need fp32 range: use bf16x3 or fp32)", precision);
+    return dweight_bx3(X, ldx, dH, ldg, n_rows, K, F, dW, lddw, workspace, as_stream(stream));
 }
 
 int ggcn_subword_pool(const float *A, int64_t sa_b, int64_t sa_r, int64_t sa_c, const float *X, int64_t x_batch,

@@ -71,6 +71,10 @@ int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, c
                        float *d_ga, float *d_gb, hipStream_t st);
 
 size_t dweight_workspace_bytes(int64_t N, int K, int F);
+size_t dweight_bx3_workspace_bytes(int64_t N, int K, int F);
+int dweight_bx3(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F, float *dW,
+                int64_t lddw, void *workspace, hipStream_t st);
+int weight_pack_rows(const float *W, int64_t ldw, int64_t K_valid, int F, int k_steps_total, void *pack, hipStream_t st);
 int dweight(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F, float *dW,
             int64_t lddw, void *workspace, hipStream_t st);
 

@@ -44,6 +44,25 @@ __global__ __launch_bounds__(128) void weight_pack_kernel(const float *__restric
     pack[(((int64_t)n_tile * k_steps + k_step) * 2 + plane) * 64 + lane] = v;
 }
 
+// the same image for k-steps [ks0, ks0 + gridDim.y) of a longer k axis
+__global__ __launch_bounds__(128) void weight_pack_slice_kernel(const float *__restrict__ W, int64_t ldw, int K, int F,
+                                                                int k_steps, int ks0, bf16x8 *__restrict__ pack)
+{
+    const int n_tile = blockIdx.x, k_step = ks0 + blockIdx.y;
+    const int plane = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = n_tile * NT + (lane & 31);
+    const int kb = k_step * KSTEP + 8 * (lane >> 5);
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kb + j;
+        const float w = (k < K && n < F) ? W[(int64_t)k * ldw + n] : 0.0f;
+        const __bf16 hi = (__bf16)w;
+        v[j] = plane == 0 ? hi : (__bf16)(w - (float)hi);
+    }
+    pack[(((int64_t)n_tile * k_steps + k_step) * 2 + plane) * 64 + lane] = v;
+}
+
 // ---- W -> f16mx8 image: per (32-column tile, 32-deep stage) [f16 frag k-step 0][k-step 1]
 // [MX operand 64 x 32 B][scales 64 x 4 B]; see f16mx8_core.h.  block = 64 threads = one wavefront.
 template <bool TR>
@@ -235,6 +254,21 @@ int weight_pack(const float *W, int64_t ldw, int K, int F, int precision, bool t
         hipLaunchKernelGGL(weight_pack_kernel<false>, dim3((unsigned)n_tiles, (unsigned)k_steps), dim3(128), 0, st, W,
                            ldw, K, F, k_steps, static_cast<bf16x8 *>(wpack));
     return check_launch("ggcn_weight_pack");
+}
+
+// bf16 hi/lo image of a [K_valid x F] matrix laid out for k_steps_total k-steps (rows past K_valid are zeros):
+// the split-K weight gradient packs dH over a node axis padded to its chunk grid (dweight_bx3.hip)
+int weight_pack_rows(const float *W, int64_t ldw, int64_t K_valid, int F, int k_steps_total, void *pack, hipStream_t st)
+{
+    const int n_tiles = round_up(F, NT) / NT;
+    if (K_valid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "weight_pack_rows: too many rows");
+    // grid.y is limited to 65535: walk the k-steps in slices
+    for (int ks0 = 0; ks0 < k_steps_total; ks0 += 65535) {
+        const int n = k_steps_total - ks0 < 65535 ? k_steps_total - ks0 : 65535;
+        hipLaunchKernelGGL(weight_pack_slice_kernel, dim3((unsigned)n_tiles, (unsigned)n), dim3(128), 0, st, W, ldw,
+                           (int)K_valid, F, k_steps_total, ks0, static_cast<bf16x8 *>(pack));
+    }
+    return check_launch("weight_pack_rows");
 }
 
 int linear_packed(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy, int64_t M,

@@ -39,7 +39,8 @@ class _GatedLayerFunction(torch.autograd.Function):
         dY, d_sg, d_ga, d_gb   HIP, one pass over the stored output (gate_pool_backward.hip)
         dH = A^T.(D.dY)        HIP, one wavefront per SOURCE node on the transposed CSR
         dX = dH.W^T            HIP bf16x3 MFMA linear on the packed W^T
-        dW = X^T.dH            HIP exact-fp32 MFMA, split over the node rows (dweight_fp32.hip)
+        dW = X^T.dH            HIP split-K: bf16x3 main loop on X^T and packed dH (dweight_bx3.hip), or the
+                               exact-fp32 MFMA form for precision 'fp32' (dweight_fp32.hip)
         db = sum_rows dY
     """
 
@@ -107,13 +108,20 @@ class _GatedLayerFunction(torch.autograd.Function):
                 dx = dx.view(B, T, K)
             if need[1]:
                 x2d = text.reshape(B * T, K)
-                if x2d.stride(1) == 1 and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0:
+                if x2d.stride(1) != 1:
+                    x2d = x2d.contiguous()
+                # split-precision layers: bf16x3 on the forward's main loop (fp32 exponent range, ~1e-5);
+                # precision "fp32": the exact fp32 MFMA form, which wants 16-byte aligned rows
+                prec = "bf16x3" if layer.precision in _capi.PACKED else "fp32"
+                aligned = x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0 and F % 4 == 0
+                if prec == "fp32" and not aligned:
+                    dw = x2d.t().matmul(dh)   # rows that cannot be 16-byte aligned: plain library GEMM
+                else:
                     dw = torch.empty(K, F, dtype=torch.float32, device=dev)
-                    ws = torch.empty(lib.ggcn_dweight_workspace_bytes(B * T, K, F), dtype=torch.uint8, device=dev)
+                    ws = torch.empty(lib.ggcn_dweight_workspace_bytes(B * T, K, F, _capi.PREC[prec]),
+                                     dtype=torch.uint8, device=dev)
                     _capi.check(lib.ggcn_dweight(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(dh), F, B * T, K, F,
-                                                 _capi.ptr(dw), F, _capi.ptr(ws), st), "ggcn_dweight")
-                else:  # odd strides: plain library GEMM
-                    dw = x2d.t().matmul(dh)
+                                                 _capi.ptr(dw), F, _capi.PREC[prec], _capi.ptr(ws), st), "ggcn_dweight")
             if ctx.has_bias and need[2]:
                 db = dy.sum(dim=0)
         return dx, dw, db, d_sg, d_ga, d_gb, None, None, None, None

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 3
+#define GGCN_ABI_VERSION 4
 
 typedef void *ggcn_stream_t;
 
@@ -146,8 +146,13 @@ int ggcn_aggregate(const float *Hd, int64_t ldh,
  *   dX = dH.W^T       ggcn_linear with the image made by ggcn_weight_pack(transposed = 1)
  *                     (packs the transpose of the stored matrix: the packed operand has
  *                     K = F_layer rows and F = K_layer columns)
- *   dW = X^T.dH       ggcn_dweight: exact fp32 MFMA, split over the node rows, deterministic
- *                     (workspace: ggcn_dweight_workspace_bytes(N, K, F) bytes)
+ *   dW = X^T.dH       ggcn_dweight, split over the node rows, deterministic (fixed-order slab sum):
+ *                     GGCN_PREC_FP32  exact fp32 MFMA on the rows as they lie;
+ *                     GGCN_PREC_BF16X3  X is transposed and dH packed once, then the forward's
+ *                     bf16x3 main loop runs split-K (about 3x faster at config 2; needs
+ *                     ~2 x 4*N*max(K,F) bytes of workspace).  f16mx8 is refused: gradients need
+ *                     the fp32 exponent range.  (workspace: ggcn_dweight_workspace_bytes(N, K, F,
+ *                     precision) bytes, 16-byte aligned)
  *   db = sum_rows dY  a plain column sum on the caller's side. */
 /* Backward of the gate / max-pool epilogue (models/bert_amir5.py:627-640): from the stored
  * layer output `out` (= y*store_gate), the gates and the upstream gradients of out and of the
@@ -160,9 +165,9 @@ int ggcn_gate_pool_backward(const float *out, int64_t ldo,
                             const float *d_out, int64_t ldd, const float *d_pa, const float *d_pb,
                             int B, int T, int F, float *dY, int64_t ldy,
                             float *d_sg, float *d_ga, float *d_gb, ggcn_stream_t stream);
-size_t ggcn_dweight_workspace_bytes(int64_t n_rows, int K, int F);
+size_t ggcn_dweight_workspace_bytes(int64_t n_rows, int K, int F, int precision);
 int ggcn_dweight(const float *X, int64_t ldx, const float *dH, int64_t ldg, int64_t n_rows, int K, int F,
-                 float *dW, int64_t lddw, void *workspace, ggcn_stream_t stream);
+                 float *dW, int64_t lddw, int precision, void *workspace, ggcn_stream_t stream);
 int ggcn_inv_denominators(const int32_t *rowptr, const float *vals, int64_t n_rows, float *inv,
                           ggcn_stream_t stream);
 int ggcn_aggregate_t(const float *G, int64_t ldg,

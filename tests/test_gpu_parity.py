@@ -661,3 +661,37 @@ def test_regulariser_folded_into_the_layer_launches(pkg, dev, B, T, H, precision
     scale = max(1.0, abs(float(ref["xy"])))
     assert abs(float(r["xy"]) - float(standalone)) <= 2e-6 * scale      # same products, another summation tree
     assert abs(float(r["xy"]) - float(ref["xy"])) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("N,K,F", [(20000, 768, 768), (5000, 132, 260), (37, 8, 12), (513, 256, 34), (1, 4, 4)])
+def test_weight_gradient_vs_float64(pkg, dev, precision, N, K, F):
+    """dW = X^T . dH (backward of gcn.py:34) through the C ABI, both forms, against float64; twice for
+    bitwise reproducibility (fixed-order slab sums, no atomics)."""
+    from ed_gated_gcn_amd import _capi
+    lib = pkg.load_library()
+    rng = np.random.default_rng(N + K)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    g = (rng.standard_normal((N, F)) * 1e-3).astype(np.float32)      # gradient-sized values
+    ref = x.astype(np.float64).T @ g.astype(np.float64)
+    xd, gd = torch.from_numpy(x).to(dev), torch.from_numpy(g).to(dev)
+    prec = _capi.PREC[precision]
+    ws = torch.empty(lib.ggcn_dweight_workspace_bytes(N, K, F, prec), dtype=torch.uint8, device=dev)
+    outs = []
+    if precision == "fp32" and (K % 4 or F % 4):      # the exact form reads 16-byte row pieces: refused, not wrong
+        dw = torch.empty(K, F, device=dev)
+        assert lib.ggcn_dweight(_capi.ptr(xd), K, _capi.ptr(gd), F, N, K, F, _capi.ptr(dw), F, prec, _capi.ptr(ws),
+                                _capi.stream_of(dev)) == 3
+        return
+    for _ in range(2):
+        dw = torch.full((K, F), float("nan"), device=dev)
+        _capi.check(lib.ggcn_dweight(_capi.ptr(xd), K, _capi.ptr(gd), F, N, K, F, _capi.ptr(dw), F, prec,
+                                     _capi.ptr(ws), _capi.stream_of(dev)), "ggcn_dweight")
+        outs.append(dw.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    scale = np.sqrt(N) * 1e-3
+    bound = {"fp32": 2e-6, "bf16x3": 3e-5}[precision] * max(scale, 1e-3)
+    assert np.max(np.abs(outs[0] - ref)) <= bound
+    rc = lib.ggcn_dweight(_capi.ptr(xd), K, _capi.ptr(gd), F, N, K, F, _capi.ptr(dw), F, _capi.PREC["f16mx8"],
+                          _capi.ptr(ws), _capi.stream_of(dev))
+    assert rc != 0 and b"range" in lib.ggcn_last_error()
