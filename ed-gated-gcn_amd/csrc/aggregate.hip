@@ -325,6 +325,216 @@ __global__ __launch_bounds__(256) void aggregate_rows(
     }
 }
 
+bool side_aligned(const float *bias, const float *sg, const float *ga, const float *gb)
+{
+    return (!bias || aligned16(bias)) && (!sg || aligned16(sg)) && (!ga || aligned16(ga)) && (!gb || aligned16(gb));
+}
+
+// ---- long graphs (kTiledMaxT < T <= kNarrowMaxT): the graph in LDS, 128 bytes of columns at a time ----
+// The direct form re-reads every source row ~deg times from L2 (config 4, PMC: HBM traffic is the
+// compulsory 0.54 GB but 2.2 GB cross L2 -> CU and the wavefronts wait 2/3 of their cycles).  Here
+// a workgroup owns (graph, 128-byte column slab): it copies the graph's T x 128 B slab into LDS once
+// (<= 96 KiB, two workgroups per CU at T = 512) and every neighbour sum reads LDS.  8 lanes of 16 B
+// cover a row of the slab, so a wavefront works on 8 destination rows at once (32 per workgroup
+// step) with per-row edge lists; pooled maxima stay in registers and meet in LDS at the end: one
+// workgroup sees all T rows, so no atomics and no pool preset.  The graph's CSR (row pointers and
+// 16-bit local column ids, <= kIdxCap edges) is staged in LDS as well, so the dependent chain
+// rowptr -> colidx -> features of every row runs on LDS latency, not on L2 latency; a graph with
+// more edges reads its indices from global memory (same code path, workgroup-uniform switch).
+// Used for fp16 features (config 4: 350 -> 250 us); with fp32 a 128-byte slab is only 32 columns and
+// the chunked direct form above stays faster (317 vs 344 us), so fp32 keeps it.
+constexpr int kNarrowMaxT = 768;  // 96 KiB of slab
+constexpr int kIdxCap = 4096;     // edges per graph whose column ids are staged (8 KiB as uint16)
+template <typename E, bool HAS_VALS, bool NORM>
+__global__ __launch_bounds__(256) void aggregate_narrow(
+    const E *__restrict__ Hd, int64_t ldh, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ colidx, const float *__restrict__ vals, const float *__restrict__ src_scale,
+    const float *__restrict__ bias, int n_graphs, int T, int F, int n_slabs,
+    const float *__restrict__ store_gate, const float *__restrict__ pool_gate_a,
+    const float *__restrict__ pool_gate_b, E *__restrict__ out, int64_t ldo,
+    float *__restrict__ pool_a, float *__restrict__ pool_b)
+{
+    constexpr int EPL = 16 / (int)sizeof(E);  // elements per lane: 4 fp32 / 8 fp16
+    constexpr int kCols = 8 * EPL;            // columns per slab (128 bytes)
+    __shared__ float red[2][kWaves][kCols];
+    __shared__ int s_rp[kNarrowMaxT + 1];        // row pointers relative to the graph's first edge
+    __shared__ unsigned short s_col[kIdxCap];    // column ids relative to the graph's first node
+    extern __shared__ __attribute__((aligned(16))) char tile_raw[];  // [T][128 B]
+    E *tile = reinterpret_cast<E *>(tile_raw);
+
+    // XCD-affine order as in the chunked form: an XCD walks through its own graphs one after the other
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / n_slabs) * 8 + xcd;
+    const int slab = slot % n_slabs;
+    if (b >= n_graphs) return;  // whole workgroup, before any barrier
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 3, piece = lane & 7;
+    const int col = slab * kCols + piece * EPL;
+    const bool live = col < F;  // F % EPL == 0 is checked on the host
+    const int64_t node0 = (int64_t)b * T;
+
+    float vb[EPL], vsg[EPL], vga[EPL], vgb[EPL], pa[EPL], pb[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        vb[k] = 0.0f; vsg[k] = 1.0f; vga[k] = 1.0f; vgb[k] = 1.0f;
+        pa[k] = -INFINITY; pb[k] = -INFINITY;
+    }
+    if (live) {
+        const int64_t g = (int64_t)b * F + col;
+        if (bias) load_f32<EPL>(bias + col, vb);
+        if (store_gate) load_f32<EPL>(store_gate + g, vsg);
+        if (pool_gate_a) load_f32<EPL>(pool_gate_a + g, vga);
+        if (pool_gate_b) load_f32<EPL>(pool_gate_b + g, vgb);
+    }
+
+    // ---- the slab's rows leave for LDS first (up to 24 x 16 B per thread in flight), the graph's CSR
+    // is fetched and staged while they travel ----
+    const int r_first = wave * 8 + grp;
+    constexpr int kMaxSteps = kNarrowMaxT / 32;
+    uint4 st4[kMaxSteps];
+#pragma unroll
+    for (int q = 0; q < kMaxSteps; ++q) {
+        const int r = r_first + 32 * q;
+        st4[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (r < T && live) st4[q] = *reinterpret_cast<const uint4 *>(Hd + (node0 + r) * ldh + col);
+    }
+    const int e_base = rowptr[node0];
+    const int nnz_g = rowptr[node0 + T] - e_base;
+    const bool staged = nnz_g <= kIdxCap;  // workgroup-uniform
+    for (int i = threadIdx.x; i <= T; i += 256) s_rp[i] = rowptr[node0 + i] - e_base;
+    if (staged)
+        for (int j = threadIdx.x; j < nnz_g; j += 256) s_col[j] = (unsigned short)(colidx[e_base + j] - (int)node0);
+#pragma unroll
+    for (int q = 0; q < kMaxSteps; ++q) {
+        const int r = r_first + 32 * q;
+        if (r < T) *reinterpret_cast<uint4 *>(tile_raw + (size_t)r * 128 + piece * 16) = st4[q];
+    }
+    __syncthreads();
+
+    // ---- neighbour sums out of LDS: this lane group's rows r_first, r_first + 32, ... ----
+    const int32_t *cg = colidx + e_base;
+    const float *vg = HAS_VALS ? vals + e_base : nullptr;
+    auto col_of = [&](int e) -> int { return staged ? (int)s_col[e] : cg[e] - (int)node0; };  // local source row
+    for (int r = r_first; r < T; r += 32) {   // rows differ per lane group: plain divergent control flow
+        const int64_t node = node0 + r;
+        int e = s_rp[r];
+        const int end = s_rp[r + 1];
+        const int cnt = end - e;
+        float acc[EPL], wsum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) acc[k] = 0.0f;
+        for (; e + 1 < end; e += 2) {  // two source rows in flight
+            const int c0 = col_of(e), c1 = col_of(e + 1);
+            float w0 = 1.0f, w1 = 1.0f;
+            if constexpr (HAS_VALS) { w0 = vg[e]; w1 = vg[e + 1]; }
+            if constexpr (!NORM) { w0 *= src_scale[node0 + c0]; w1 *= src_scale[node0 + c1]; }
+            float h0[EPL], h1[EPL];
+            Seg<E, EPL>::load(tile + (size_t)c0 * kCols + piece * EPL, h0);
+            Seg<E, EPL>::load(tile + (size_t)c1 * kCols + piece * EPL, h1);
+            if constexpr (HAS_VALS || !NORM) {
+#pragma unroll
+                for (int k = 0; k < EPL; ++k) acc[k] = fmaf(w1, h1[k], fmaf(w0, h0[k], acc[k]));
+                wsum += w0;
+                wsum += w1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < EPL; ++k) acc[k] = (acc[k] + h0[k]) + h1[k];
+            }
+        }
+        if (e < end) {
+            const int c0 = col_of(e);
+            float w0 = 1.0f;
+            if constexpr (HAS_VALS) w0 = vg[e];
+            if constexpr (!NORM) w0 *= src_scale[node0 + c0];
+            float h0[EPL];
+            Seg<E, EPL>::load(tile + (size_t)c0 * kCols + piece * EPL, h0);
+            if constexpr (HAS_VALS || !NORM) {
+#pragma unroll
+                for (int k = 0; k < EPL; ++k) acc[k] = fmaf(w0, h0[k], acc[k]);
+                wsum += w0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < EPL; ++k) acc[k] += h0[k];
+            }
+        }
+        const float inv = NORM ? 1.0f / ((HAS_VALS ? wsum : (float)cnt) + 1.0f) : 1.0f;  // gcn.py:35
+        if (live) {
+            float o[EPL];
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                const float y = NORM ? acc[k] * inv + vb[k] : acc[k];  // gcn.py:41,43
+                o[k] = y * vsg[k];
+                pa[k] = fmaxf(pa[k], y * vga[k]);
+                pb[k] = fmaxf(pb[k], y * vgb[k]);
+            }
+            if (out) Seg<E, EPL>::store(out + node * ldo + col, o);
+        }
+    }
+
+    if (pool_a || pool_b) {
+        // the 8 lane groups of a wavefront hold the same columns: butterfly over the group index
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+#pragma unroll
+            for (int d = 8; d <= 32; d <<= 1) {
+                pa[k] = fmaxf(pa[k], __shfl_xor(pa[k], d));
+                pb[k] = fmaxf(pb[k], __shfl_xor(pb[k], d));
+            }
+        }
+        if (grp == 0) {
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                red[0][wave][piece * EPL + k] = pa[k];
+                red[1][wave][piece * EPL + k] = pb[k];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kCols) {
+            const int tcol = slab * kCols + threadIdx.x;
+            if (tcol < F) {
+                float ma = red[0][0][threadIdx.x], mb = red[1][0][threadIdx.x];
+#pragma unroll
+                for (int w = 1; w < kWaves; ++w) {
+                    ma = fmaxf(ma, red[0][w][threadIdx.x]);
+                    mb = fmaxf(mb, red[1][w][threadIdx.x]);
+                }
+                if (pool_a) pool_a[(int64_t)b * F + tcol] = ma;
+                if (pool_b) pool_b[(int64_t)b * F + tcol] = mb;
+            }
+        }
+    }
+}
+
+// true (and launched) when the narrow-tile form applies: 16-byte pieces, kTiledMaxT < T <= kNarrowMaxT
+template <typename E, bool NORM>
+bool launch_narrow(const E *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx, const float *vals,
+                   const float *src_scale, const float *bias, int B, int T, int F, const float *sg, const float *ga,
+                   const float *gb, E *out, int64_t ldo, float *pa, float *pb, hipStream_t st, int &rc)
+{
+    constexpr int EPL = 16 / (int)sizeof(E);
+    if (T <= kTiledMaxT || T > kNarrowMaxT) return false;
+    if ((F % EPL) || (ldh % EPL) || !aligned16(Hd) || (out && ((ldo % EPL) || !aligned16(out)))) return false;
+    if (!side_aligned(bias, sg, ga, gb)) return false;
+    const int n_slabs = (F + 8 * EPL - 1) / (8 * EPL);
+    const int64_t blocks = ((int64_t)B + 7) / 8 * 8 * n_slabs;
+    if (blocks > (int64_t)INT32_MAX) return false;
+    const size_t lds = (size_t)T * 128;
+    auto go = [&](auto kern) {
+        static bool raised = false;  // dynamic LDS above the default 64 KiB limit needs the attribute once
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kNarrowMaxT * 128);
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, Hd, ldh, rowptr, colidx, vals, src_scale, bias,
+                           B, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb);
+    };
+    if (vals) go(aggregate_narrow<E, true, NORM>);
+    else go(aggregate_narrow<E, false, NORM>);
+    rc = check_launch(NORM ? "ggcn_aggregate" : "ggcn_aggregate_t");
+    return true;
+}
+
 template <typename E, int VEC>
 int launch(const E *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
            const float *vals, const float *bias, int B, int T, int F, const float *sg,
@@ -397,11 +607,6 @@ __global__ __launch_bounds__(256) void inv_denominator_kernel(const int32_t *__r
     inv[i] = 1.0f / s;
 }
 
-bool side_aligned(const float *bias, const float *sg, const float *ga, const float *gb)
-{
-    return (!bias || aligned16(bias)) && (!sg || aligned16(sg)) && (!ga || aligned16(ga)) && (!gb || aligned16(gb));
-}
-
 int check_args(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx, int B, int T, int F,
                const void *out, int64_t ldo, const float *pool_a, const float *pool_b)
 {
@@ -459,6 +664,12 @@ int aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_
     if (int rc = check_args(Hd, ldh, rowptr, colidx, B, T, F, out, ldo, pool_a, pool_b)) return rc;
     const __half *h = static_cast<const __half *>(Hd);
     __half *o = static_cast<__half *>(out);
+    {
+        int rc = GGCN_OK;
+        if (launch_narrow<__half, true>(h, ldh, rowptr, colidx, vals, nullptr, bias, B, T, F, store_gate, pool_gate_a,
+                                        pool_gate_b, o, ldo, pool_a, pool_b, st, rc))
+            return rc;
+    }
     const bool vec = (F % 8 == 0) && (ldh % 8 == 0) && aligned16(Hd) && (!out || ((ldo % 8 == 0) && aligned16(out))) &&
                      side_aligned(bias, store_gate, pool_gate_a, pool_gate_b);
 #if defined(GGCN_HALF_VEC8)

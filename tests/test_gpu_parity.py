@@ -695,3 +695,26 @@ def test_weight_gradient_vs_float64(pkg, dev, precision, N, K, F):
     rc = lib.ggcn_dweight(_capi.ptr(xd), K, _capi.ptr(gd), F, N, K, F, _capi.ptr(dw), F, _capi.PREC["f16mx8"],
                           _capi.ptr(ws), _capi.stream_of(dev))
     assert rc != 0 and b"range" in lib.ggcn_last_error()
+
+
+@pytest.mark.parametrize("T,degree,weighted", [(512, 10.0, False), (300, 5.0, True), (64, 3.0, True), (49, 48.0, False)])
+def test_fp16_long_graphs_lds_slab_form(pkg, dev, T, degree, weighted):
+    """fp16 features, 48 < T <= 768: the graph's 128-byte column slab and its CSR live in LDS.  Covers
+    > 4096 edges per graph (indices stay in global memory), edge weights, and a dense graph."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(T)
+    B, H = 3, 136
+    adj = synth.dependency_batch(B, T, min(degree, T), seed=T, lengths=np.array([T, T - 7, T // 2]))
+    if weighted:
+        adj = adj * rng.uniform(0.25, 2.0, size=adj.shape).astype(np.float32)
+    x16 = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32)).half()
+    g = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32)))
+    w, b = synth.layer_params(H, H, seed=5)
+    ref = ref_dense.graph_convolution(x16.float(), torch.from_numpy(adj), torch.from_numpy(w), torch.from_numpy(b))
+    m = _layer(pkg, dev, w, b, "bf16x3")
+    with torch.no_grad():
+        out, pa, pb = m.forward_gated(x16.to(dev), torch.from_numpy(adj).to(dev), store_gate=g.to(dev),
+                                      pool_gate_a=g.to(dev), want_pool_a=True, want_pool_b=True)
+    np.testing.assert_allclose(out.float().cpu().numpy(), (ref * g[:, None, :]).numpy(), rtol=0, atol=3e-3)
+    np.testing.assert_allclose(pa.cpu().numpy(), (ref * g[:, None, :]).max(dim=1)[0].numpy(), rtol=0, atol=3e-3)
+    np.testing.assert_allclose(pb.cpu().numpy(), ref.max(dim=1)[0].numpy(), rtol=0, atol=3e-3)
