@@ -127,7 +127,8 @@ __device__ __forceinline__ void store_elem(float *p, float v) { *p = v; }
 __device__ __forceinline__ void store_elem(__half *p, float v) { *p = __float2half_rn(v); }
 
 // ET: element type of X and Y (float, or __half with fp32 accumulation); SCH: 0 = bf16x3, 1 = f16mx8
-template <int SCH, typename ET, bool AVEC, bool KFULL>
+// VST (fp32 output, F and ldy multiples of 4, Y 16-byte aligned): 16-byte row stores through LDS
+template <int SCH, typename ET, bool AVEC, bool KFULL, bool VST>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_bf16x3_kernel(
     const ET *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
     ET *__restrict__ Y, int64_t ldy, int64_t M, int K, int F, int m_tiles, int n_wg, int k_steps)
@@ -163,6 +164,40 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_bf16x3_kernel(
 
 #ifndef GGCN_LAB_NO_STORE
     const bool full_rows = m0 + BM <= M;  // workgroup-uniform: the row guard only exists in the last tile
+    if constexpr (VST) {
+        static_assert(!VST || RN == 2, "the staged epilogue is written for 64 columns per wavefront");
+        // fp32 output as 16-byte row stores: each 32-row block of this wavefront's 64 columns is staged in
+        // its 8 KiB of the (idle) A buffers and leaves as 4 rows x 256 contiguous bytes per instruction
+        // (same scheme as the fused layer's epilogue: rows with bit 2 set swap their 32-column halves so
+        // that the two lane halves hit different banks)
+        float *stage_lds = reinterpret_cast<float *>(lds) + wave * (32 * 64);
+        const int c = lane & 31, h = lane >> 5;
+        const int colq = (lane & 15) * 4;
+        const int gcol = nt0 * NT + colq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row0 = (r & 3) + 8 * (r >> 2);
+                    stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = acc[i][j][r];
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int64_t gm0 = m0 + wm * 128 + i * 32;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = 4 * it + (lane >> 4);
+                const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 64 + (colq ^ (32 * ((row >> 2) & 1)))]);
+                if ((full_rows || gm0 + row < M) && gcol < F)
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Y) + (gm0 + row) * ldy + gcol) = v4;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
         const int gn = (nt0 + j) * NT + (lane & 31);
@@ -206,12 +241,14 @@ int launch_linear(const ET *X, int64_t ldx, const void *wpack, ET *Y, int64_t ld
     const int64_t grid = grid_for(m_tiles, n_wg);
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_linear(bf16x3): M too large");
     const char *wp = static_cast<const char *>(wpack);
-#define GGCN_LAUNCH(AV, KF)                                                                                     \
-    hipLaunchKernelGGL((linear_bf16x3_kernel<SCH, ET, AV, KF>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, \
-                       wp, Y, ldy, M, K, F, (int)m_tiles, n_wg, k_steps)
-    if (avec && kfull) GGCN_LAUNCH(true, true);
-    else if (avec) GGCN_LAUNCH(true, false);
-    else GGCN_LAUNCH(false, false);
+    const bool vst = std::is_same<ET, float>::value && (F % 4 == 0) && (ldy % 4 == 0) && aligned16(Y);
+#define GGCN_LAUNCH(AV, KF, VS)                                                                                     \
+    hipLaunchKernelGGL((linear_bf16x3_kernel<SCH, ET, AV, KF, VS && std::is_same<ET, float>::value>), dim3((unsigned)grid), \
+                       dim3(kThreads), 0, st, X, ldx, wp, Y, ldy, M, K, F, (int)m_tiles, n_wg, k_steps)
+    if (avec && kfull && vst) GGCN_LAUNCH(true, true, true);
+    else if (avec && kfull) GGCN_LAUNCH(true, true, false);
+    else if (avec) GGCN_LAUNCH(true, false, false);
+    else GGCN_LAUNCH(false, false, false);
 #undef GGCN_LAUNCH
     return check_launch("ggcn_linear(bf16x3)");
 }
