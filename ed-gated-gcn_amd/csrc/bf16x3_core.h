@@ -1,4 +1,4 @@
-// Shared main loop of the bf16x3 matrix kernels (linear_bf16x3.hip, fused_layer.hip).
+// Shared main loop of the bf16x3 matrix kernels (linear_split.hip, fused_layer.hip).
 //
 //   acc[128 x 64 per wavefront] += A[128 rows, K] (fp32, split on the fly) . Wpack[K, 256 cols]
 //

@@ -4,7 +4,7 @@
 // gfx950 has an f32-input MFMA, v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered
 // fp32 fmaf chain (one rounding per product), at the f32 vector rate
 // (~155 TFLOP/s chip-wide).  This is the GGCN_PREC_FP32 mode: the tightest
-// parity with the reference's fp32 matmul; GGCN_PREC_BF16X3 (linear_bf16x3.hip)
+// parity with the reference's fp32 matmul; GGCN_PREC_BF16X3 (linear_split.hip)
 // is the fast mode.
 //
 // Tiling: workgroup 256 threads = 4 wavefronts (2 x 2), tile 128 x 128 x 16;

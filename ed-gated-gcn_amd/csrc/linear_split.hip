@@ -1,4 +1,5 @@
-// Dense linear at ~fp32 accuracy on the bf16 matrix cores (GGCN_PREC_BF16X3):
+// Dense linear at ~fp32 accuracy on the low-precision matrix cores (GGCN_PREC_BF16X3 and
+// GGCN_PREC_F16MX8; the second scheme is described in f16mx8_core.h):
 //     Y[M,F] = X[M,K] . W[K,F]          (models/gcn.py:34)
 //
 // Why: at hidden=768 the layer is GEMM-bound, not HBM-bound: 154.6
@@ -11,8 +12,8 @@
 // 1e-4 parity gate, at 1/3 of the bf16 rate (833 TFLOP/s ceiling instead of 155).
 //
 // Kernel shape, operand lane maps and the measured scheduling notes: bf16x3_core.h (the main
-// loop is shared with fused_layer.hip).  This file adds the weight packer and the plain-store
-// epilogue.
+// loop is shared with fused_layer.hip).  This file adds the weight packers of both schemes and the
+// store epilogue (16-byte row stores through LDS for aligned fp32 output).
 #include "f16mx8_core.h"
 
 namespace ggcn {
@@ -129,7 +130,7 @@ __device__ __forceinline__ void store_elem(__half *p, float v) { *p = __float2ha
 // ET: element type of X and Y (float, or __half with fp32 accumulation); SCH: 0 = bf16x3, 1 = f16mx8
 // VST (fp32 output, F and ldy multiples of 4, Y 16-byte aligned): 16-byte row stores through LDS
 template <int SCH, typename ET, bool AVEC, bool KFULL, bool VST>
-__global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_bf16x3_kernel(
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_split_kernel(
     const ET *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
     ET *__restrict__ Y, int64_t ldy, int64_t M, int K, int F, int m_tiles, int n_wg, int k_steps)
 {
@@ -243,7 +244,7 @@ int launch_linear(const ET *X, int64_t ldx, const void *wpack, ET *Y, int64_t ld
     const char *wp = static_cast<const char *>(wpack);
     const bool vst = std::is_same<ET, float>::value && (F % 4 == 0) && (ldy % 4 == 0) && aligned16(Y);
 #define GGCN_LAUNCH(AV, KF, VS)                                                                                     \
-    hipLaunchKernelGGL((linear_bf16x3_kernel<SCH, ET, AV, KF, VS && std::is_same<ET, float>::value>), dim3((unsigned)grid), \
+    hipLaunchKernelGGL((linear_split_kernel<SCH, ET, AV, KF, VS && std::is_same<ET, float>::value>), dim3((unsigned)grid), \
                        dim3(kThreads), 0, st, X, ldx, wp, Y, ldy, M, K, F, (int)m_tiles, n_wg, k_steps)
     if (avec && kfull && vst) GGCN_LAUNCH(true, true, true);
     else if (avec && kfull) GGCN_LAUNCH(true, true, false);
