@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --graphs per GPU; strong: --graphs in total, sharded (BASELINE configs[2])")
     ap.add_argument("--unfused", action="store_true", help="force linear + aggregate (2 launches per layer)")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2: consecutive steps alternate between two HIP streams, so the tail and the launch gap of "
+                         "one step's kernels are filled by the next step's (about +4 %% edges/s, DESIGN.md 5); the "
+                         "per-launch figures of `roofline` are then taken from a single-stream pass after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to "
                     "rehearse the N>1 code path on a one-GPU box together with --same-device")
@@ -147,9 +151,22 @@ def main():
     gather = shard.PooledGather([B] * world, H, dev) if world > 1 else None
     pending = []
 
+    side = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    counter = [0]
+
     def step():
         with torch.no_grad():
-            r = pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2)
+            if side is None:
+                r = pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2)
+            else:   # independent batches: step i runs on stream i % 2 (the inputs are read-only)
+                with torch.cuda.stream(side[counter[0] % args.streams]):
+                    r = pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2)
+                    if world > 1:
+                        if pending:
+                            gather.finish(pending.pop())
+                        pending.append(gather.start(r["out"]))
+                counter[0] += 1
+                return r
             if world > 1:
                 if pending:
                     gather.finish(pending.pop())      # step i-1's gather: done or nearly done
@@ -189,6 +206,17 @@ def main():
     elapsed = time.perf_counter() - t0
     gc1.forward_gated, gc2.forward_gated = plain
     t_layer_in_loop = statistics.mean(a.elapsed_time(b) for a, b in layer_events) * 1e-3   # seconds per layer launch
+    if side is not None:
+        # two steps in flight: a launch's events also span the other stream's kernels, so the per-launch
+        # time comes from a short single-stream pass over the same inputs
+        side, layer_events = None, []
+        gc1.forward_gated, gc2.forward_gated = with_events(plain[0]), with_events(plain[1])
+        for _ in range(max(10, min(args.steps, 50))):
+            with torch.no_grad():
+                pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2)
+        torch.cuda.synchronize(dev)
+        gc1.forward_gated, gc2.forward_gated = plain
+        t_layer_in_loop = statistics.mean(a.elapsed_time(b) for a, b in layer_events) * 1e-3
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -287,6 +315,7 @@ def main():
                                    % (B, T, args.degree, nnz, H),
                        "graphs_total": B_total, "precision": args.precision,
                        "path": "fused (1 launch/layer)" if fused_path else "linear + aggregate (2 launches/layer)",
+                       "streams": args.streams,
                        "collective": "all_gather(out[B,H])" if world > 1 else "none"},
             "edge_layers_per_sec": 2 * value,
             "forward_algorithmic_bytes": fwd_bytes,
