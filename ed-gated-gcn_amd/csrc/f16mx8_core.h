@@ -42,7 +42,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int STAGE_PACK_BYTES = 2 * 1024 + 64 * 32 + 64 * 4;  // 4352
+constexpr int STAGE_PACK_BYTES = 2 * 1024 + 64 * 16 + 64 * 4;  // 3328
 constexpr int XL_SHIFT = 11;                                    // xl is stored as xl * 2^11
 constexpr int SCALE_XL = 127 - XL_SHIFT, SCALE_XH = 127;
 
@@ -171,19 +171,35 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             b1[j] = *reinterpret_cast<const f16x8 *>(p + 1024);
         }
     };
-    auto load_bq = [&](int st, i32x8 (&b)[RN], int (&sc)[RN]) {  // MX operand + scales of stage st
+    auto load_bq = [&](int st, i32x4 (&b)[RN], int (&sc)[RN]) {  // fp8 residual operand + scales of stage st
         st = st < stages_packed ? st : stages_packed - 1;
 #ifdef GGCN_MX_LAB_BFIX
         st = 0;
 #endif
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
-            const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES + 2048 + lane * 16;  // lane * 32 in all
-            const i32x4 lo = *reinterpret_cast<const i32x4 *>(p);
-            const i32x4 hi = *reinterpret_cast<const i32x4 *>(p + 16);
-            b[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            sc[j] = *reinterpret_cast<const int *>(bbase[j] + (int64_t)st * STAGE_PACK_BYTES + 4096 - lane * 12);
+            const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES;  // bbase already holds lane * 16
+            b[j] = *reinterpret_cast<const i32x4 *>(p + 2048);
+            sc[j] = *reinterpret_cast<const int *>(p + 3072 - lane * 12);  // + lane * 4
         }
+    };
+    // fp8(wh * 2^s0) of this lane's 16 fp16 values (its two fragments): byte 1 of the scale dword is the
+    // E8M0 scale of block 0 (byte 0 is the scale the MFMA reads for this lane's own block)
+    auto wh8_of = [&](const f16x8 &f0, const f16x8 &f1, int sc) -> i32x4 {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        const float inv = __builtin_bit_cast(float, (sc & 0xff00) << 15);  // 2^(byte - 127): the converts DIVIDE by it
+        i32x4 o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const f16x8 &f = d < 2 ? f0 : f1;
+            const int e = (d & 1) * 4;
+            s2 q = {0, 0};
+            q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, h2{f[e], f[e + 1]}, inv, false);
+            q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, h2{f[e + 2], f[e + 3]}, inv, true);
+            o[d] = __builtin_bit_cast(int, q);
+        }
+        return o;
     };
 
     const int f_row = wm * 128 + (lane & 31);
@@ -198,9 +214,10 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     auto read_q = [&](int buf, int i, i32x8 &a) {
         const char *q_plane = lds + buf * (2 * BM * ROWB) + BM * ROWB;
         const int row = f_row + i * 32;
-        // k = 16h .. 16h+15 as {xl8 x4, xh8 x4} groups: even dwords -> block 0 (xl), odd dwords -> block 1 (xh)
-        const i32x4 lo = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, 2 * f_half));
-        const i32x4 hi = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, 2 * f_half + 1));
+        // k = 8h..8h+7 and 16+8h..16+8h+7 (the k of this lane half's fp16 fragments) as {xl8 x4, xh8 x4}
+        // groups: even dwords -> block 0 (xl), odd dwords -> block 1 (xh)
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, f_half));
+        const i32x4 hi = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, 2 + f_half));
         a = i32x8{lo[0], lo[2], hi[0], hi[2], lo[1], lo[3], hi[1], hi[3]};
     };
 
@@ -212,7 +229,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     f16x8 b0[RN], b1[RN];
-    i32x8 bq[RN];
+    i32x4 bq[RN];  // fp8(wl) of the stage
     int sq[RN];
 #ifdef GGCN_MX_LAB_KDIV  // timing probe: 1/KDIV of the main loop, same prologue and epilogue
     const int stages = (K + BK - 1) / BK / GGCN_MX_LAB_KDIV;
@@ -275,15 +292,24 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[1], acc[i][1], 0, 0, 0);
             GGCN_SB();
         }
+        // the MX operand of W = {fp8(wh) made here from the fp16 fragments, fp8(wl) as loaded}; b0/b1 are
+        // dead afterwards and take the next stage's fragments
+        i32x8 bm[RN];
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const i32x4 w = wh8_of(b0[j], b1[j], sq[j]);
+            bm[j] = i32x8{w[0], w[1], w[2], w[3], bq[j][0], bq[j][1], bq[j][2], bq[j][3]};
+        }
+        GGCN_SB();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < 3) read_q(buf, i + 1, aq[(i + 1) & 1]);
             GGCN_SB();
-            acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bq[0], acc[i][0], 0, 0, 0, scale_a, 0, sq[0]);
+            acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[0], acc[i][0], 0, 0, 0, scale_a, 0, sq[0]);
             GGCN_SB();
             if (i == 0) load_bf(kstage(st + 1), b0, b1);  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
             GGCN_SB();
-            acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bq[1], acc[i][1], 0, 0, 0, scale_a, 0, sq[1]);
+            acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[1], acc[i][1], 0, 0, 0, scale_a, 0, sq[1]);
             GGCN_SB();
         }
 #ifndef GGCN_MX_LAB_NOBAR

@@ -85,12 +85,14 @@ __global__ __launch_bounds__(64) void weight_pack_mx8_kernel(const float *__rest
         for (int j = 0; j < 8; ++j) v[j] = (_Float16)wat(32 * st + 16 * s2 + 8 * h + j);
         *reinterpret_cast<mx8::f16x8 *>(base + s2 * 1024 + lane * 16) = v;
     }
-    // MX operand: lane (c, h): bytes 0-15 = block 0 = fp8(wh * 2^s0), bytes 16-31 = block 1 = fp8(wl * 2^s1),
-    // both for k = 32 st + 16 h + jj; one power-of-two scale per (column, block) over the 32 k of the stage
+    // fp8 operand of the correction: block 0 = fp8(wh * 2^s0) is made in the main loop from the fp16
+    // fragments; stored here is block 1 = fp8(wl * 2^s1), lane (c, h): bytes 0-7 <-> k = 32 st + 8h + j,
+    // bytes 8-15 <-> k = 32 st + 16 + 8h + j (the k of the lane's two fp16 fragments); one power-of-two
+    // scale per (column, block) over the 32 k of the stage
     float wh[16], wl[16], m0 = 0.0f, m1 = 0.0f;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
-        const float w = wat(32 * st + 16 * h + jj);
+        const float w = wat(32 * st + 16 * (jj >> 3) + 8 * h + (jj & 7));
         wh[jj] = (float)(_Float16)w;
         wl[jj] = w - wh[jj];
         m0 = fmaxf(m0, fabsf(wh[jj]));
@@ -106,22 +108,20 @@ __global__ __launch_bounds__(64) void weight_pack_mx8_kernel(const float *__rest
         return s > 100 ? 100 : (s < -100 ? -100 : s);
     };
     const int s0 = shift_for(m0), s1 = shift_for(m1);
-    int q[8];
+    int q[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        int a = 0, b = 0;
-        a = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wh[4 * t], s0), ldexpf(wh[4 * t + 1], s0), a, false);
-        a = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wh[4 * t + 2], s0), ldexpf(wh[4 * t + 3], s0), a, true);
-        b = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wl[4 * t], s1), ldexpf(wl[4 * t + 1], s1), b, false);
-        b = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wl[4 * t + 2], s1), ldexpf(wl[4 * t + 3], s1), b, true);
-        q[t] = a;
-        q[4 + t] = b;
+        int b8 = 0;
+        b8 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wl[4 * t], s1), ldexpf(wl[4 * t + 1], s1), b8, false);
+        b8 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wl[4 * t + 2], s1), ldexpf(wl[4 * t + 3], s1), b8, true);
+        q[t] = b8;
     }
-    int *mxp = reinterpret_cast<int *>(base + 2048 + lane * 32);
+    int *mxp = reinterpret_cast<int *>(base + 2048 + lane * 16);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) mxp[t] = q[t];
-    // lane c carries the scale of block 0, lane c + 32 the scale of block 1 (E8M0: value = 2^(byte-127))
-    *reinterpret_cast<int *>(base + 4096 + lane * 4) = 127 - (h ? s1 : s0);
+    for (int t = 0; t < 4; ++t) mxp[t] = q[t];
+    // E8M0 (value = 2^(byte-127)): byte 0 = the scale of this lane's block for the MFMA (lane c: block 0,
+    // lane c + 32: block 1), byte 1 = the scale of block 0 for the in-loop fp16 -> fp8 conversion
+    *reinterpret_cast<int *>(base + 3072 + lane * 4) = ((127 - s0) << 8) | (127 - (h ? s1 : s0));
 }
 
 __device__ __forceinline__ void store_elem(float *p, float v) { *p = v; }
