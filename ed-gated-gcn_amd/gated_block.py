@@ -38,6 +38,13 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2):
     Returns the tensors the reference block produces:
     ``gcn1`` (ungated, feeds layer 2), ``x1``, ``y1``, ``xy``, ``x`` (gated layer-2 output), ``out``.
     """
+    if x.shape[0] == 0:   # empty batch: what the reference's ops give on empty tensors (the mean of nothing is nan)
+        gc1._check(x)
+        B, T, F = 0, x.shape[1], gc2.out_features
+        z2 = x.new_zeros((0, F), dtype=torch.float32)
+        return {"gcn1": x.new_zeros((0, T, gc1.out_features)), "x1": x.new_zeros((0, gc1.out_features)),
+                "y1": x.new_zeros((0, gc1.out_features)), "xy": x.new_full((), float("nan")),
+                "x": x.new_zeros((0, T, F)), "out": z2}
     csr = adj if isinstance(adj, BatchedCSR) else gc1._as_csr(adj, x)
     training = torch.is_grad_enabled() and (gc1._needs_grad(x, gate1, gate2) or gc2._needs_grad(x, gate2))
     if (not training and gc1.takes_fused_path(x, csr) and gc2.takes_fused_path(x, csr)

@@ -718,3 +718,20 @@ def test_fp16_long_graphs_lds_slab_form(pkg, dev, T, degree, weighted):
     np.testing.assert_allclose(out.float().cpu().numpy(), (ref * g[:, None, :]).numpy(), rtol=0, atol=3e-3)
     np.testing.assert_allclose(pa.cpu().numpy(), (ref * g[:, None, :]).max(dim=1)[0].numpy(), rtol=0, atol=3e-3)
     np.testing.assert_allclose(pb.cpu().numpy(), ref.max(dim=1)[0].numpy(), rtol=0, atol=3e-3)
+
+
+def test_empty_batch_like_the_reference(pkg, dev):
+    """B = 0 is a valid input of gcn.py:30-45 (empty output, no kernel launch); the reference block's mean over
+    an empty batch is nan."""
+    from ed_gated_gcn_amd import synth
+    H = 16
+    w, b = synth.layer_params(H, H, seed=1)
+    l1, l2 = _layer(pkg, dev, w, b, "f16mx8"), _layer(pkg, dev, w, b, "f16mx8")
+    x = torch.zeros(0, 5, H, device=dev)
+    adj = torch.zeros(0, 5, 5, device=dev)
+    ref = ref_dense.graph_convolution(x.cpu(), adj.cpu(), torch.from_numpy(w), torch.from_numpy(b))
+    with torch.no_grad():
+        out = l1(x, adj)
+        r = pkg.gated_gcn_block(x, adj, torch.zeros(0, H, device=dev), torch.zeros(0, H, device=dev), l1, l2)
+    assert tuple(out.shape) == tuple(ref.shape) == (0, 5, H)
+    assert tuple(r["x"].shape) == (0, 5, H) and tuple(r["out"].shape) == (0, H) and bool(torch.isnan(r["xy"]))
