@@ -103,6 +103,9 @@ def time_variants(what, names):
         if ref is None:
             ref = res
         print("%-24s max|diff vs %s| = %.3g" % (n, names[0], float((res - ref).abs().max())))
+    for _ in range(150):          # precondition: the chip needs ~50 ms of load to settle
+        run(names[0])
+    torch.cuda.synchronize()
     times = {n: [] for n in names}
     for rnd in range(12):
         for n in names:
