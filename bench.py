@@ -292,7 +292,8 @@ def main():
         agg_bytes = layer_bytes - 4 * H * H
         lin_tf = lin_flops / t_lin / 1e12
         if t_lin >= t_agg:
-            roofline = {"kernel": "linear_split_kernel (%s)" % args.precision, "bound": "mfma", "achieved": lin_tf,
+            roofline = {"kernel": "linear_fp32_kernel" if args.precision == "fp32" else "linear_split_kernel (%s)" % args.precision,
+                        "bound": "mfma", "achieved": lin_tf,
                         "peak": lin_peak, "unit": "TFLOP/s", "frac": lin_tf / lin_peak,
                         "traffic": measured.get("linear_split_kernel:" + args.precision), "avg_launch_us": t_lin * 1e6}
         else:
