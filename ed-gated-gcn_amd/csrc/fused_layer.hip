@@ -1,7 +1,7 @@
 // One gated-GCN layer in ONE launch, for graphs of at most 32 nodes with a binary adjacency
 // (the reference's case: ACE sentences, ORI_ML = 31, 0/1 dependency matrices, graph.py:66-74):
 //
-//   hidden = X.W                                   models/gcn.py:34        bf16x3 MFMA main loop
+//   hidden = X.W                                   models/gcn.py:34        f16mx8 / bf16x3 main loop
 //   agg    = adj.hidden                            models/gcn.py:41        MFMA on the accumulator
 //   y      = agg / (rowsum(adj)+1) + bias          models/gcn.py:35,41,43  registers
 //   out    = y * store_gate ; pools = max_t(y*g)   models/bert_amir5.py:627-640
@@ -14,7 +14,8 @@
 // with ADJ_g the graph's 0/1 matrix as an exact bf16 A operand, expanded in registers from a
 // 32-bit row mask (BatchedCSR.rowmask: bit j of word i = edge i<-j; 4 B per node), and
 // hidden split into two bf16 planes (residual 2^-17 |hidden|, ~4e-6 after the mean).
-// Cost: 4 MFMAs per tile on top of the 144 of the main loop (+3 %), no LDS, no extra pass.
+// Cost: 4 MFMAs per tile on top of the main loop's 72 (f16mx8) or 144 (bf16x3), no extra pass; the
+// [N,F] output is staged through the idle A buffers in LDS so that it leaves as 16-byte row stores.
 // k order inside a step: element j of lane half h is node 16s + 8(j>>2) + 4h + (j&3) for both
 // operands (the register->row map of the accumulator), so no data moves between lanes.
 //
