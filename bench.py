@@ -36,10 +36,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--precondition", type=int, default=150,
+    ap.add_argument("--precondition", type=int, default=-1,
                     help="untimed steps run before the warm-up: the chip needs ~0.1 s of load to settle (measured: "
                          "the first ~60 steps after an idle period run 4.5 %% slower, DESIGN.md 5); the W warm-up "
-                         "steps and the K timed steps follow as the contract says")
+                         "steps and the K timed steps follow as the contract says.  -1 (default): adaptive -- "
+                         "windows of 50 steps until two consecutive windows agree within 1 %% (at least 150, at most "
+                         "2000 steps)")
     ap.add_argument("--graphs", type=int, default=4096, help="graphs per GPU (config 2: 4096)")
     ap.add_argument("--tokens", type=int, default=32)
     ap.add_argument("--hidden", type=int, default=768)
@@ -185,7 +187,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.precondition + args.warmup):
+    n_pre = args.precondition
+    if n_pre < 0:   # adaptive: run until the step time has settled (same count on every rank: rank 0 decides)
+        n_pre, last = 0, None
+        while n_pre < 2000:
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                step()
+            sync_all()
+            dt = time.perf_counter() - t0
+            n_pre += 50
+            settled = last is not None and abs(dt - last) <= 0.01 * dt and n_pre >= 150
+            if world > 1:
+                flag = torch.tensor([1 if settled else 0], device=dev)
+                dist.broadcast(flag, src=0)
+                settled = bool(flag.item())
+            last = dt
+            if settled:
+                break
+    else:
+        for _ in range(n_pre):
+            step()
+    for _ in range(args.warmup):
         step()
     sync_all()
     # HIP events around every layer launch INSIDE the timed region (torch's current stream is the
@@ -320,7 +344,7 @@ def main():
                                    % (B, T, args.degree, nnz, H),
                        "graphs_total": B_total, "precision": args.precision,
                        "path": "fused (1 launch/layer)" if fused_path else "linear + aggregate (2 launches/layer)",
-                       "streams": args.streams, "precondition_steps": args.precondition,
+                       "streams": args.streams, "precondition_steps": n_pre,
                        "collective": "all_gather(out[B,H])" if world > 1 else "none"},
             "edge_layers_per_sec": 2 * value,
             "forward_algorithmic_bytes": fwd_bytes,
