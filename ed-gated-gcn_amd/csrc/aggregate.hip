@@ -103,11 +103,14 @@ struct Seg<__half, 1> {
     static __device__ __forceinline__ void store(__half *p, const float (&v)[1]) { *p = __float2half_rn(v[0]); }
 };
 
-// max for floats through integer atomics (order-independent, hence deterministic): non-negative
-// values order like signed ints, negative ones like unsigned ints reversed.  -inf is the identity.
+// max for floats through integer atomics (order-independent, hence deterministic): values with a
+// clear sign bit order like signed ints, values with the sign bit set like unsigned ints reversed.
+// -inf is the identity.  The branch is on the SIGN BIT, not on v >= 0: -0.0 (what y * gate gives for
+// a gate that dropout zeroed, bert_amir5.py:623-625) must take the unsigned-min side, where
+// 0x80000000 beats the -inf preset 0xFF800000; as a signed max it is INT_MIN and never wins.
 __device__ __forceinline__ void atomic_max_float(float *p, float v)
 {
-    if (v >= 0.0f) atomicMax(reinterpret_cast<int *>(p), __float_as_int(v));
+    if (__float_as_int(v) >= 0) atomicMax(reinterpret_cast<int *>(p), __float_as_int(v));
     else atomicMin(reinterpret_cast<unsigned int *>(p), __float_as_uint(v));
 }
 

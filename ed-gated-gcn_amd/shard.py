@@ -44,8 +44,11 @@ class PooledGather:
     """All-gather of per-rank pooled outputs [B_r, H] into [sum B_r, H] (uneven B_r allowed).
 
     ``start`` launches the collective asynchronously and returns a handle; ``finish`` waits for it
-    and returns the gathered tensor.  Two buffers alternate, so step i's gather can overlap step
-    i+1's kernels (the collective runs on RCCL's own stream)."""
+    and returns the gathered tensor.  Two slots alternate -- each with its OWN output buffer and its
+    own padded send buffer -- so step i's gather can overlap step i+1's kernels (the collective runs
+    on RCCL's own stream).  A slot is never rewritten while a collective launched from it may still
+    be reading: ``start`` first waits for the slot's previous collective (a no-op when the caller
+    already ``finish``-ed it, as the bench loop does)."""
 
     def __init__(self, counts, width, device, dtype=torch.float32, group=None):
         self.counts = [int(c) for c in counts]
@@ -54,22 +57,35 @@ class PooledGather:
         self.uniform = len(set(self.counts)) == 1
         self.max_count = max(self.counts)
         self.bufs = [torch.empty(self.world * self.max_count, width, device=device, dtype=dtype) for _ in range(2)]
-        self.pad = None if self.uniform else torch.zeros(self.max_count, width, device=device, dtype=dtype)
+        self.pads = [None, None] if self.uniform else \
+            [torch.zeros(self.max_count, width, device=device, dtype=dtype) for _ in range(2)]
+        self.inflight = [None, None]   # the last collective launched from each slot
         self.turn = 0
 
     def start(self, pooled):
-        buf = self.bufs[self.turn]
+        slot = self.turn
         self.turn ^= 1
+        prev = self.inflight[slot]
+        if prev is not None:           # the slot's buffers are still the operands of that collective
+            prev.wait()
+        buf = self.bufs[slot]
         src = pooled
         if not self.uniform:  # pad to the largest shard so one fixed-size collective serves every rank
-            self.pad[:pooled.shape[0]].copy_(pooled)
-            src = self.pad
-        work = dist.all_gather_into_tensor(buf, src.contiguous(), group=self.group, async_op=True)
-        return work, buf
+            pad = self.pads[slot]
+            pad[:pooled.shape[0]].copy_(pooled)
+            src = pad
+        elif not src.is_contiguous():
+            src = src.contiguous()
+        work = dist.all_gather_into_tensor(buf, src, group=self.group, async_op=True)
+        self.inflight[slot] = work
+        return work, buf, src          # src is kept alive by the handle until finish()
 
     def finish(self, handle):
-        work, buf = handle
+        work, buf = handle[0], handle[1]
         work.wait()
+        for s in range(2):
+            if self.inflight[s] is work:
+                self.inflight[s] = None
         if self.uniform:
             return buf
         parts = [buf[r * self.max_count: r * self.max_count + c] for r, c in enumerate(self.counts)]

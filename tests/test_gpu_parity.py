@@ -735,3 +735,39 @@ def test_empty_batch_like_the_reference(pkg, dev):
         r = pkg.gated_gcn_block(x, adj, torch.zeros(0, H, device=dev), torch.zeros(0, H, device=dev), l1, l2)
     assert tuple(out.shape) == tuple(ref.shape) == (0, 5, H)
     assert tuple(r["x"].shape) == (0, 5, H) and tuple(r["out"].shape) == (0, H) and bool(torch.isnan(r["xy"]))
+
+
+# ---------------------------------------------------------------- gates that dropout zeroed (bert_amir5.py:623-625)
+@pytest.mark.parametrize("precision,fused", MODES, ids=MODE_IDS)
+@pytest.mark.parametrize("T", [64, 32, 9])
+def test_zero_gates_pool_to_signed_zero_not_minus_inf(pkg, dev, precision, fused, T):
+    """A gate entry that is exactly 0 (train-mode dropout on the gate) makes y*gate = -0.0 on every row
+    whose y is negative; max_t of a column of -0.0 must be 0, never the -inf preset of the chunked
+    aggregation's atomic max (T > 48 with fp32 features takes that path)."""
+    from ed_gated_gcn_amd import synth
+    B, H = 5, 64
+    rng = np.random.default_rng(11)
+    adj = synth.dependency_batch(B, T, 3.0, seed=2)
+    x = rng.standard_normal((B, T, H)).astype(np.float32)
+    w, b = synth.layer_params(H, H, seed=3)
+    b[:] = -50.0                                   # every y is negative on every row
+    g1 = rng.uniform(0.1, 0.9, (B, H)).astype(np.float32)
+    g2 = rng.uniform(0.1, 0.9, (B, H)).astype(np.float32)
+    g1[:, ::3] = 0.0
+    g2[::2, :] = 0.0
+    g2[1, 5] = -0.0
+    t = torch.from_numpy
+    y = ref_dense.graph_convolution(t(x), t(adj.astype(np.float32)), t(w), t(b))      # gcn.py:30-45
+    ref = {"pool_a": torch.max(y * t(g1)[:, None, :], 1)[0],                           # bert_amir5.py:627,635
+           "pool_b": torch.max(y * t(g2)[:, None, :], 1)[0]}
+    assert float(y.max()) < 0
+    m = _layer(pkg, dev, w, b, precision, fused)
+    with torch.no_grad():
+        out, pa, pb = m.forward_gated(t(x).to(dev), t(adj).to(dev), pool_gate_a=t(g1).to(dev), pool_gate_b=t(g2).to(dev),
+                                      want_pool_a=True, want_pool_b=True)
+    torch.cuda.synchronize()
+    for got, want in ((pa, ref["pool_a"]), (pb, ref["pool_b"])):
+        got = got.cpu().numpy()
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, want.numpy(), rtol=0, atol=50 * TOL[precision])   # |y| ~ 50
+    assert (pa.cpu().numpy()[:, ::3] == 0).all() and (pb.cpu().numpy()[::2] == 0).all()
