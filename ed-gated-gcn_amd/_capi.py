@@ -24,6 +24,9 @@ PROTOTYPES = {
     "ggcn_csr_rowmask": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_layer_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                  c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "ggcn_block_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                 c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "ggcn_overlap_reduce": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_subword_pool": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                                   c_i32, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_weight_pack_bytes": (c_sz, [c_i32, c_i32, c_i32]),
@@ -44,7 +47,7 @@ PROTOTYPES = {
     "ggcn_gate_overlap": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2}
 PACKED = ("bf16x3", "f16mx8")  # precisions whose linear reads a ggcn_weight_pack image
 FLAG_WEIGHTED = 1

@@ -82,32 +82,18 @@ __device__ __forceinline__ int stage_row(int p) { return p * Geom<AT>::RPP + (in
 // 8 XCDs; inside an XCD the first 32 blocks take the 32 CUs in order, the next 32 become their
 // co-residents, and a finished block is replaced by the block 64 slots later.
 //   * the column tiles of one row block sit on neighbouring CUs of ONE XCD at the same time, so
-//     they share that row block's A rows through the XCD's L2;
-//   * (GGCN_PAIR_MAP) the two co-resident blocks of a CU work on the SAME column tile of two
-//     neighbouring row blocks, so the second one finds the B fragments in the CU's L1.
+//     they share that row block's A rows through the XCD's L2.
 __device__ __forceinline__ bool tile_of_block(int id, int m_tiles, int n_wg, int &m_tile, int &n_wgi)
 {
     const int xcd = id & 7, slot = id >> 3;
-#if defined(GGCN_PAIR_MAP)
-    const int half = (slot >> 5) & 1;
-    const int p = ((slot >> 6) << 5) | (slot & 31);
-    n_wgi = p % n_wg;
-    m_tile = ((p / n_wg) * 2 + half) * 8 + xcd;
-#else
     m_tile = (slot / n_wg) * 8 + xcd;
     n_wgi = slot % n_wg;
-#endif
     return m_tile < m_tiles;
 }
 inline int64_t grid_for(int64_t m_tiles, int n_wg)
 {
     const int64_t per_xcd = (m_tiles + 7) / 8;          // row blocks per XCD
-#if defined(GGCN_PAIR_MAP)
-    const int64_t pairs = (per_xcd + 1) / 2 * n_wg;     // (row-block pair, column tile) items
-    return (pairs + 31) / 32 * 64 * 8;
-#else
     return per_xcd * n_wg * 8;
-#endif
 }
 
 __device__ __forceinline__ float elem_to_float(float v) { return v; }
@@ -118,14 +104,8 @@ template <typename AT>
 __device__ __forceinline__ void load16(const AT *p, float (&v)[Geom<AT>::EPT])
 {
     if constexpr (sizeof(AT) == 4) {
-#if defined(GGCN_A_NT)
-        typedef float f32x4v __attribute__((ext_vector_type(4)));
-        const f32x4v t = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(p));
-        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-#else
         const float4 t = *reinterpret_cast<const float4 *>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-#endif
     } else {
         const uint4 t = *reinterpret_cast<const uint4 *>(p);
         const __half2 *h = reinterpret_cast<const __half2 *>(&t);
@@ -178,36 +158,6 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         const int row = stage_row<AT>(i);
         const int off = a_lds_off(row, s_k >> 3) + (s_k & 4) * 2;
         const int gk = k0 + s_k;
-#if defined(GGCN_SPLIT_PAIRWISE)
-        // pairwise: hi pair = one v_cvt_pk_bf16_f32; float(hi) = the two halves of that dword
-        // (shift / mask); lo pair = one more v_cvt_pk of the two residuals  -> 6 VALU per pair.
-        // Fewer instructions than the per-element form below, but measured SLOWER (fused 492 vs
-        // 462 us, same process): kept for reference only.
-        uint32_t hw[EPT / 2], lw[EPT / 2];
-#pragma unroll
-        for (int c = 0; c < EPT; c += 2) {
-            float x0 = ra[i][c], x1 = ra[i][c + 1];
-            if constexpr (!KFULL || ZROWS) {
-                bool in0 = true, in1 = true;
-                if constexpr (!KFULL) { in0 = gk + c < K; in1 = gk + c + 1 < K; }
-                if constexpr (ZROWS) { in0 = in0 && avalid[i]; in1 = in1 && avalid[i]; }
-                x0 = in0 ? x0 : 0.0f;
-                x1 = in1 ? x1 : 0.0f;
-            }
-            const bf16x2 h = {(__bf16)x0, (__bf16)x1};
-            const uint32_t hb = __builtin_bit_cast(uint32_t, h);
-            const bf16x2 l = {(__bf16)(x0 - __uint_as_float(hb << 16)), (__bf16)(x1 - __uint_as_float(hb & 0xffff0000u))};
-            hw[c / 2] = hb;
-            lw[c / 2] = __builtin_bit_cast(uint32_t, l);
-        }
-        if constexpr (EPT == 4) {
-            *reinterpret_cast<uint2 *>(hi_plane + off) = make_uint2(hw[0], hw[1]);
-            *reinterpret_cast<uint2 *>(lo_plane + off) = make_uint2(lw[0], lw[1]);
-        } else {
-            *reinterpret_cast<uint4 *>(hi_plane + off) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-            *reinterpret_cast<uint4 *>(lo_plane + off) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-        }
-#else
         __bf16 hi[EPT], lo[EPT];
 #pragma unroll
         for (int c = 0; c < EPT; ++c) {
@@ -228,7 +178,6 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             *reinterpret_cast<bf16x8 *>(hi_plane + off) = bf16x8{hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
             *reinterpret_cast<bf16x8 *>(lo_plane + off) = bf16x8{lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
         }
-#endif
     };
 
     // B fragments straight from the packed image; indices clamped, never predicated: a column
@@ -253,44 +202,20 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     const int f_half = lane >> 5;
     // one 32-row block of one k-step: 2 LDS fragment reads + 6 MFMAs (3 products x 2 column tiles)
     auto mma_block = [&](int buf, int s, int i, const bf16x8 (&b)[RN][2]) {
-#if !defined(GGCN_LAB_NO_IGLP)
         // LLVM's MFMA/DS interleave strategy for this scheduling region: measured -4 % on the fused
         // layer (448 vs 467 us, same process, three orderings)
         __builtin_amdgcn_iglp_opt(0);
-#endif
         const char *hi_plane = lds + buf * (2 * BM * ROWB);
         const char *lo_plane = hi_plane + BM * ROWB;
         const int off = a_lds_off(f_row + i * 32, s * 2 + f_half);
         const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(hi_plane + off);
         const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(lo_plane + off);
-#if defined(GGCN_LAB_MFMA16)
-        // TIMING-ONLY experiment (wrong results): same flops as 16x16x32 instructions, to see what
-        // clock the chip holds on that shape (MI355X_MICROARCH.md DVFS item 7)
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int j = 0; j < RN; ++j) {
-            f32x4 q[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) q[t] = f32x4{acc[i][j][4 * t], acc[i][j][4 * t + 1], acc[i][j][4 * t + 2], acc[i][j][4 * t + 3]};
-            q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b[j][0], q[0], 0, 0, 0);
-            q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b[j][0], q[1], 0, 0, 0);
-            q[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b[j][1], q[2], 0, 0, 0);
-            q[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b[j][1], q[3], 0, 0, 0);
-            q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b[j][0], q[0], 0, 0, 0);
-            q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b[j][0], q[1], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][4 * t + e] = q[t][e];
-        }
-#else
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][1], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b[j][0], acc[i][j], 0, 0, 0);
         }
-#endif
     };
 
 #pragma unroll
@@ -337,22 +262,12 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
                 store_a_pass(buf ^ 1, i + 4, k_next1);
                 load_a_pass(i + 4, ka);
             }
-#if !defined(GGCN_LAB_NO_SB)
             __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         load_b(st * KS + 2, b0);
-#if !defined(GGCN_LAB_NO_SB2)
         __builtin_amdgcn_sched_barrier(0);
-#endif
-#if defined(GGCN_LAB_PRIO)
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) mma_block(buf, 1, i, b1);
-#if defined(GGCN_LAB_PRIO)
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __syncthreads();  // the only barrier of the stage
     };
     int st = 0;

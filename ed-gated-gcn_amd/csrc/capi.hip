@@ -65,6 +65,21 @@ int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint3
                        ldo, pool_a, pool_b, overlap_partial, overlap_in, overlap_out, precision, as_stream(stream));
 }
 
+int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const uint32_t *rowmask,
+                     const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
+                     const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
+                     float *x1, float *y1, float *pool_out, float *overlap_partial, int precision,
+                     ggcn_stream_t stream)
+{
+    return block_fused(X, ldx, wpack1, wpack12, rowmask, bias1, bias_mid, bias2, B, T, K, F, gate1, gate2, gcn1, ld1,
+                       x_out, ld2, x1, y1, pool_out, overlap_partial, precision, as_stream(stream));
+}
+
+int ggcn_overlap_reduce(const float *partials, int B, int F, float *xy, ggcn_stream_t stream)
+{
+    return overlap_reduce(partials, B, F, xy, as_stream(stream));
+}
+
 size_t ggcn_weight_pack_bytes(int K, int F, int precision) { return weight_pack_bytes(K, F, precision); }
 
 int ggcn_weight_pack(const float *W, int64_t ldw, int K, int F, int precision, int transposed, void *wpack,

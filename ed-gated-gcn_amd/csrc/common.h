@@ -65,6 +65,12 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
                 const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,
                 float *overlap_partial, const float *overlap_in, float *overlap_out, int precision, hipStream_t st);
 
+int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const uint32_t *rowmask,
+                const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
+                const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
+                float *x1, float *y1, float *pool_out, float *overlap_partial, int precision, hipStream_t st);
+int overlap_reduce(const float *partials, int B, int F, float *xy, hipStream_t st);
+
 int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                        const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                        const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,

@@ -113,9 +113,6 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 
     float ra[NP][EPT];
     auto load_a_pass = [&](int i, int k0) {
-#ifdef GGCN_MX_LAB_AFIX  // timing probe: every stage reads the first 32 k of its rows (L1 hits)
-        k0 = 0;
-#endif
         const int gk = k0 + s_k;
         if constexpr (AVEC) {
             load16<AT>(arow[i] + ((KFULL || gk < K) ? gk : 0), ra[i]);
@@ -167,9 +164,6 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     }
     auto load_bf = [&](int st, f16x8 (&b0)[RN], f16x8 (&b1)[RN]) {  // fp16 fragments of both k-steps of stage st
         st = st < stages_packed ? st : stages_packed - 1;
-#ifdef GGCN_MX_LAB_BFIX  // timing probe: every stage reads the B image of stage 0 (L1 hits)
-        st = 0;
-#endif
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES;
@@ -179,9 +173,6 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     };
     auto load_bq = [&](int st, i32x4 (&b)[RN], int (&sc)[RN]) {  // fp8 residual operand + scales of stage st
         st = st < stages_packed ? st : stages_packed - 1;
-#ifdef GGCN_MX_LAB_BFIX
-        st = 0;
-#endif
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES;  // bbase already holds lane * 16
@@ -237,11 +228,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     f16x8 b0[RN], b1[RN];
     i32x4 bq[RN];  // fp8(wl) of the stage
     int sq[RN];
-#ifdef GGCN_MX_LAB_KDIV  // timing probe: 1/KDIV of the main loop, same prologue and epilogue
-    const int stages = (K + BK - 1) / BK / GGCN_MX_LAB_KDIV;
-#else
     const int stages = (K + BK - 1) / BK;
-#endif
 
     // n-th stage of this workgroup's loop -> stage of the K axis (n past the end repeats the last one)
     auto kstage = [&](int n) {
@@ -318,9 +305,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[1], acc[i][1], 0, 0, 0, scale_a, 0, sq[1]);
             GGCN_SB();
         }
-#ifndef GGCN_MX_LAB_NOBAR
         __syncthreads();
-#endif
     };
     int st = 0;
     for (; st + 1 < stages; st += 2) {

@@ -1,5 +1,6 @@
-// One gated-GCN layer in ONE launch, for graphs of at most 32 nodes with a binary adjacency
-// (the reference's case: ACE sentences, ORI_ML = 31, 0/1 dependency matrices, graph.py:66-74):
+// One gated-GCN layer -- or the reference's whole two-layer gated block -- in ONE launch, for graphs of
+// at most 32 nodes with a binary adjacency (the reference's case: ACE sentences, ORI_ML = 31, 0/1
+// dependency matrices, graph.py:66-74):
 //
 //   hidden = X.W                                   models/gcn.py:34        f16mx8 / bf16x3 main loop
 //   agg    = adj.hidden                            models/gcn.py:41        MFMA on the accumulator
@@ -19,15 +20,54 @@
 // k order inside a step: element j of lane half h is node 16s + 8(j>>2) + 4h + (j&3) for both
 // operands (the register->row map of the accumulator), so no data moves between lanes.
 //
+// THE BLOCK IN ONE LAUNCH (ggcn_block_fused).  bert_amir5.py:626-640 feeds gc2 with the UNGATED gcn1 and
+// applies no non-linearity in between (gcn.py:19 declares a Tanh and never uses it), so with
+// D = diag(1/(rowsum(A)+1)):
+//     gcn1 = D.A.X.W1 + 1.b1^T
+//     gcn2 = D.A.gcn1.W2 + 1.b2^T = D.A.( D.A.(X.W12) + 1.c^T ) + 1.b2^T,   W12 = W1.W2,  c = W2^T.b1
+// Both layers are then products of the SAME input X: one grid covers the column tiles of [W1 | W12]; the
+// W1 tiles end in the layer-1 epilogue (pools x1, y1 and the regulariser's partial sums; gcn1 itself is
+// written only if the caller asks for it), the W12 tiles apply the adjacency twice ("mid" bias c in
+// between) and end in the layer-2 epilogue (x = gate2*gcn2 stored, pool out).  gcn1 never makes its
+// 4.N.F-byte round trip through HBM and X is read once for both layers; flops are unchanged (W12 and c
+// are made once per weight update by the exact-fp32 linear).
+//
 // HBM traffic per layer = X in + out + 4 B/node masks + gates + W: the algorithmic bytes.
 // Graphs with T < 32 occupy a 32-row slot (rows >= T read as zeros, are never stored and never
 // pooled); T > 32 or weighted adjacency -> the unfused path (linear + aggregate.hip).
 #include "f16mx8_core.h"
+#include "lab_hooks.h"
 
 namespace ggcn {
 namespace {
 
 using namespace bx3;
+
+// what one group of column tiles ("part") computes: part 0 = the layer itself (or layer 1 of the block),
+// part 1 = layer 2 of the block through W12
+struct LayerPart {
+    const char *wpack;          // ggcn_weight_pack image of this part's [K, F] matrix
+    const float *bias;          // added after the (last) normalised aggregation, or NULL
+    const float *mid;           // NULL: one aggregation.  Else: y = D.A.(D.A.h + mid) + bias
+    const float *store_gate;    // [B,F] or NULL (ones)
+    const float *pool_gate_a;   // [B,F] or NULL (ones)
+    const float *pool_gate_b;
+    float *out;                 // [N, ldo] or NULL
+    float *pool_a, *pool_b;     // [B,F] or NULL
+    float *ov_partial;          // [B, ceil(F/64)] or NULL: sum_f pool_a*pool_b per graph and 64 columns
+    int ldo;
+};
+
+struct FusedArgs {
+    const float *X;
+    int64_t ldx;
+    const uint32_t *rowmask;
+    const float *ov_in;         // partials an EARLIER launch wrote: block 0 reduces them to *ov_out first
+    float *ov_out;
+    int B, T, K, F;
+    int g_tiles, n_wg, n_parts, k_steps;
+    LayerPart part[2];
+};
 
 // acc -> two bf16 planes (hi + lo, residual <= 2^-17 |v|) as B-operand fragments of the two k-steps
 __device__ __forceinline__ void split2(const f32x16 &acc, bf16x8 (&frag)[2][2])
@@ -43,61 +83,72 @@ __device__ __forceinline__ void split2(const f32x16 &acc, bf16x8 (&frag)[2][2])
         }
 }
 
-// FULLT: T == 32 and B % 4 == 0 (every row of every tile is a real node): drops every guard.
-#ifdef GGCN_LAB_TRACE  // timeline probe: per workgroup {block, HW_ID, XCC_ID, t0, t1, t2, t3} in 10 ns ticks
-__device__ unsigned long long ggcn_trace_buf[8192 * 8];
-#define GGCN_TRACE(slot)                                                              \
-    do {                                                                              \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) ggcn_trace_buf[blockIdx.x * 8 + (slot)] = wall_clock64(); \
-    } while (0)
-#else
-#define GGCN_TRACE(slot) do { } while (0)
-#endif
+// ADJ_g . t for one 32x32 tile: 4 MFMAs (2 planes x 2 k-steps), small plane first
+__device__ __forceinline__ f32x16 adj_times(const bf16x8 (&af)[2], const f32x16 &t)
+{
+    bf16x8 hfrag[2][2];
+    split2(t, hfrag);
+    f32x16 y;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = 0.0f;
+#pragma unroll
+    for (int p = 1; p >= 0; --p)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], hfrag[p][s], y, 0, 0, 0);
+    return y;
+}
+
+// mean_b sum_f of the per-(graph, 64-column group) partials, in a fixed order (deterministic); one workgroup
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int n_part, int B, float *__restrict__ dst,
+                                                float *red)
+{
+    float sdot = 0.0f;
+    for (int idx = threadIdx.x; idx < n_part; idx += kThreads) sdot += part[idx];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sdot += __shfl_xor(sdot, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sdot;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
+    __syncthreads();
+}
 
 // SCH: 0 = bf16x3 main loop, 1 = f16mx8 (f16mx8_core.h)
+// FULLT: T == 32 and B % 4 == 0 (every row of every tile is a real node): drops every guard.
 // VST: the [N,F] output leaves through LDS as 16-byte row stores (needs F, ldo multiples of 4 and a 16-byte aligned out)
 template <int SCH, bool AVEC, bool KFULL, bool FULLT, bool VST>
-__global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
-    const float *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
-    const uint32_t *__restrict__ rowmask, const float *__restrict__ bias, int B, int T, int K, int F,
-    const float *__restrict__ store_gate, const float *__restrict__ pool_gate_a,
-    const float *__restrict__ pool_gate_b, float *__restrict__ out, int ldo,
-    float *__restrict__ pool_a, float *__restrict__ pool_b, float *__restrict__ ov_partial,
-    const float *__restrict__ ov_in, float *__restrict__ ov_out, int g_tiles, int n_wg, int k_steps)
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(const FusedArgs a)
 {
-#if defined(GGCN_LAB_LDS_PAD)
-    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes + GGCN_LAB_LDS_PAD];  // occupancy experiment
-#else
     __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-#endif
+    const int B = a.B, T = a.T, K = a.K, F = a.F;
     // bert_amir5.py:638 for the launch BEFORE this one on the stream: block 0 adds the per-(graph,
     // 64-column group) partial dot products that launch left in ov_in, in a fixed order
-    if (ov_in && blockIdx.x == 0) {
-        float *red = reinterpret_cast<float *>(lds);
-        const int n_part = B * ((F + 63) / 64);
-        float sdot = 0.0f;
-        for (int idx = threadIdx.x; idx < n_part; idx += kThreads) sdot += ov_in[idx];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) sdot += __shfl_xor(sdot, d);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sdot;
-        __syncthreads();
-        if (threadIdx.x == 0) *ov_out = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
-        __syncthreads();
-    }
-    const int vid = blockIdx.x;
+    if (a.ov_in && blockIdx.x == 0) reduce_partials(a.ov_in, B * ((F + 63) / 64), B, a.ov_out, reinterpret_cast<float *>(lds));
     int g_tile, n_wgi;
-    if (!tile_of_block(vid, g_tiles, n_wg, g_tile, n_wgi)) return;
-#ifdef GGCN_LAB_ONLY_N0  // probe: only the first column tile of every row block runs (how much of X is fetched once?)
-    if (n_wgi != 0) return;
-#endif
-#ifdef GGCN_LAB_TRACE
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
-        ggcn_trace_buf[blockIdx.x * 8 + 0] = blockIdx.x;
-        ggcn_trace_buf[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_REG_HW_ID
-        ggcn_trace_buf[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // HW_REG_XCC_ID
+    bool second = false;
+    if (a.n_parts == 1) {
+        if (!tile_of_block(blockIdx.x, a.g_tiles, a.n_wg, g_tile, n_wgi)) return;
+    } else {
+        // Two parts: the block ids that share an XCD (id & 7; observed dispatch, speed only) all work on the
+        // SAME part -- four XCDs take the W1 tiles, four the W12 tiles -- so that each XCD's 4 MiB L2 holds one
+        // weight image for the whole launch.  (Both images side by side, 3.7-5 MB, do not fit: with the column
+        // tiles of both parts mixed on every XCD the main loop ran 17 % slower, W streaming from beyond L2.)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        second = xcd >= 4;
+        g_tile = (slot / a.n_wg) * 4 + (xcd & 3);
+        n_wgi = slot % a.n_wg;
+        if (g_tile >= a.g_tiles) return;
     }
+    GGCN_TRACE_IDS();
     GGCN_TRACE(3);
-#endif
+    // the part this workgroup's column tiles belong to (workgroup-uniform: scalar selects)
+    const LayerPart &lp = a.part[second ? 1 : 0];
+    const char *__restrict__ wpack = lp.wpack;
+    const float *__restrict__ bias = lp.bias, *__restrict__ mid = lp.mid;
+    const float *__restrict__ store_gate = lp.store_gate;
+    const float *__restrict__ pool_gate_a = lp.pool_gate_a, *__restrict__ pool_gate_b = lp.pool_gate_b;
+    float *__restrict__ out = lp.out, *__restrict__ pool_a = lp.pool_a, *__restrict__ pool_b = lp.pool_b;
+    float *__restrict__ ov_partial = lp.ov_partial;
+    const int ldo = lp.ldo;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -118,7 +169,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
         const int g = gt0 + (row >> 5), r = row & 31;
         avalid[i] = (g < B) && (FULLT || r < T);
         const int64_t node = avalid[i] ? (int64_t)g * T + r : 0;  // clamped, zeroed by the select
-        arow[i] = X + node * ldx;
+        arow[i] = a.X + node * a.ldx;
     }
     // this lane's adjacency row (node lane&31) of each of the 4 graphs: in flight under the main loop
     uint32_t mask[4];
@@ -126,34 +177,21 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
     for (int i = 0; i < 4; ++i) {
         const int g = g0 + i;
         const bool ok = (g < B) && (FULLT || (lane & 31) < T);
-        const uint32_t m = rowmask[ok ? (int64_t)g * T + (lane & 31) : 0];
+        const uint32_t m = a.rowmask[ok ? (int64_t)g * T + (lane & 31) : 0];
         mask[i] = ok ? m : 0u;
     }
 
     f32x16 acc[4][RN];
     GGCN_TRACE(4);
-#if defined(GGCN_LAB_PHASE)  // timing probe (wrong results): half the K loop for the odd row blocks of the first
-                             // (PHASE=1) or the last (PHASE=2, control) round: does a half-period phase shift pay?
-    const bool lab_short = (g_tile & 1) && (GGCN_LAB_PHASE == 1 ? blockIdx.x < 512 : blockIdx.x + 512 >= gridDim.x);
-    const int K_loop = lab_short ? K / 2 : K;
-#else
-    const int K_loop = K;
-#endif
     if constexpr (SCH == 0)
-        bx3::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K_loop, k_steps, wm, nt0, n_tiles_total, lds, acc);
+        bx3::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, a.k_steps, wm, nt0, n_tiles_total, lds, acc);
     else
-#ifdef GGCN_MX_LAB_ROT
-        mx8::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K_loop, k_steps / 2, wm, nt0, n_tiles_total, lds, acc,
-                                                  (n_wgi * GGCN_MX_LAB_ROT) % ((K_loop + BK - 1) / BK));
-#else
-        mx8::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K_loop, k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
-#endif
-
+        mx8::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
     GGCN_TRACE(5);
-    const int c = lane & 31, h = lane >> 5;
 
+    const int c = lane & 31, h = lane >> 5;
     // bias and the gates of the 4 graphs x 2 column tiles: all loads issued together, one latency
-    float vb[RN], vsg[4][RN], vga[4][RN], vgb[4][RN];
+    float vb[RN], vmid[RN], vsg[4][RN], vga[4][RN], vgb[4][RN];
     bool col_ok[RN];
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
@@ -161,6 +199,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
         col_ok[j] = gn < F;
         const int gnc = col_ok[j] ? gn : 0;
         vb[j] = bias ? bias[gnc] : 0.0f;
+        vmid[j] = mid ? mid[gnc] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t at = (int64_t)(g0 + i < B ? g0 + i : 0) * F + gnc;
@@ -173,6 +212,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
     // the A buffers are free after the main loop's last barrier: 8 KiB per wavefront = 32 rows x 64 columns
     float *stage_lds = reinterpret_cast<float *>(lds) + wave * (32 * 64);
     const int perm_base = 16 * h;          // ds_bpermute byte address of lane 4h (+ 4*row0 per register)
+    const bool vst = VST && out != nullptr;  // workgroup-uniform
 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -190,6 +230,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
                 const uint32_t two = (mh >> b) & 3u;
                 af[s].w[q] = (two & 1u) * 0x3F80u + (two >> 1) * 0x3F800000u;  // bf16 1.0 = 0x3F80
             }
+        const bf16x8 afv[2] = {af[0].v, af[1].v};
         // 1 / (rowsum(adj) + 1) of node lane&31 (gcn.py:35): one IEEE division per node, then the
         // value of row row0 + 4h is fetched per accumulator register through the LDS crossbar
         const float inv = 1.0f / (float)(__popc(mask[i]) + 1);
@@ -206,16 +247,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
             if (nt0 + j >= n_tiles_total) break;  // wavefront-uniform: column tile past F
             const int gn = (nt0 + j) * NT + c;
 
-            bf16x8 hfrag[2][2];
-            split2(acc[i][j], hfrag);
-            f32x16 y;
+            f32x16 y = adj_times(afv, acc[i][j]);                                     // gcn.py:41 (layer 1 / the layer)
+            if (mid) {  // workgroup-uniform: the block's second layer through W12 = W1.W2 (header)
+                f32x16 u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = 0.0f;
-#pragma unroll
-            for (int p = 1; p >= 0; --p)  // small plane first
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s].v, hfrag[p][s], y, 0, 0, 0);
+                for (int r = 0; r < 16; ++r) u[r] = y[r] * rinv[r] + vmid[j];          // D.A.(X.W12) + c
+                y = adj_times(afv, u);                                                 // gcn.py:41 of layer 2
+            }
 
             // a gate is constant over the rows of a graph and rounding is monotonic, so
             // max_t fl(y_t * g) == fl(g * max_t y_t) for g >= 0 (and g * min_t y_t for g < 0):
@@ -227,7 +265,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
                 const float v = y[r] * rinv[r] + vb[j];   // gcn.py:41,43
-                if (VST) {
+                if (vst) {
                     // staged for the 16-byte row stores below; columns of the rows with bit 2 set are
                     // swapped between the two 32-column halves so that h = 0 / 1 hit different banks
                     stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = v * sg;
@@ -253,7 +291,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
             for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
             if (lane == 0) ov_partial[(int64_t)g * ((F + 63) / 64) + (nt0 >> 1)] = dot;
         }
-        if (VST) {
+        if (vst) {
             // rows of 64 columns (both column tiles of this wavefront) leave as 16 B per lane: one
             // instruction stores 4 rows x 256 contiguous bytes instead of 2 rows x 128 B
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -274,6 +312,44 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(
     GGCN_TRACE(6);
 }
 
+// bert_amir5.py:638 after ggcn_block_fused: the per-(graph, 64-column group) partials -> one scalar.
+// One workgroup of 1024 threads, 16-byte loads with four independent sums per thread (config 2: 196 KB in
+// ~3 us; the 256-thread scalar loop took 67 us), fixed summation order: deterministic.
+constexpr int kRedThreads = 1024;
+__global__ __launch_bounds__(kRedThreads) void overlap_reduce_kernel(const float *__restrict__ part, int n_part, int B,
+                                                                     float *__restrict__ dst)
+{
+    __shared__ float red[kRedThreads / 64];
+    const int tid = threadIdx.x;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    const int n4 = (reinterpret_cast<uintptr_t>(part) & 15u) == 0 ? n_part / 4 : 0;   // float4 pieces
+    const float4 *p4 = reinterpret_cast<const float4 *>(part);
+    int i = tid;
+    for (; i + 3 * kRedThreads < n4; i += 4 * kRedThreads) {
+        const float4 a = p4[i], b = p4[i + kRedThreads], c = p4[i + 2 * kRedThreads], d = p4[i + 3 * kRedThreads];
+        s0 += (a.x + a.y) + (a.z + a.w);
+        s1 += (b.x + b.y) + (b.z + b.w);
+        s2 += (c.x + c.y) + (c.z + c.w);
+        s3 += (d.x + d.y) + (d.z + d.w);
+    }
+    for (; i < n4; i += kRedThreads) {
+        const float4 a = p4[i];
+        s0 += (a.x + a.y) + (a.z + a.w);
+    }
+    for (int j = 4 * n4 + tid; j < n_part; j += kRedThreads) s1 += part[j];
+    float sdot = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sdot += __shfl_xor(sdot, d);
+    if ((tid & 63) == 0) red[tid >> 6] = sdot;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kRedThreads / 64; ++w) t += red[w];
+        *dst = t / (float)B;
+    }
+}
+
 // rowmask from a batched CSR (T <= 32): one thread per node
 __global__ __launch_bounds__(256) void rowmask_kernel(const int32_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ colidx, int64_t n, int T,
@@ -287,14 +363,61 @@ __global__ __launch_bounds__(256) void rowmask_kernel(const int32_t *__restrict_
     rowmask[i] = m;
 }
 
+// shared argument checks + launch of layer_fused_kernel for 1 or 2 parts
+int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
+{
+    if (precision != GGCN_PREC_BF16X3 && precision != GGCN_PREC_F16MX8)
+        return fail(GGCN_EUNSUPPORTED, "%s: precision %d (use bf16x3 or f16mx8)", who, precision);
+    if (!a.X || !a.rowmask) return fail(GGCN_EINVAL, "%s: null input pointer", who);
+    if (a.B <= 0 || a.T <= 0 || a.K <= 0 || a.F <= 0)
+        return fail(GGCN_EINVAL, "%s: B=%d T=%d K=%d F=%d must be positive", who, a.B, a.T, a.K, a.F);
+    if (a.T > 32) return fail(GGCN_EUNSUPPORTED, "%s: T=%d > 32; use ggcn_linear + ggcn_aggregate", who, a.T);
+    if (a.ldx < a.K) return fail(GGCN_EINVAL, "%s: ldx < K", who);
+    bool vst = true, any_out = false;
+    for (int p = 0; p < a.n_parts; ++p) {
+        const LayerPart &lp = a.part[p];
+        if (!lp.wpack) return fail(GGCN_EINVAL, "%s: null weight image", who);
+        if (!aligned16(lp.wpack)) return fail(GGCN_EINVAL, "%s: wpack must be 16-byte aligned", who);
+        if (!lp.out && !lp.pool_a && !lp.pool_b) return fail(GGCN_EINVAL, "%s: no output requested", who);
+        if (lp.out) {
+            if (lp.ldo < a.F) return fail(GGCN_EINVAL, "%s: leading dimension of the output too small", who);
+            if ((int64_t)a.T * lp.ldo >= (int64_t)INT32_MAX)
+                return fail(GGCN_EUNSUPPORTED, "%s: T*ldo does not fit 32-bit offsets", who);
+            any_out = true;
+            vst = vst && (a.F % 4 == 0) && (lp.ldo % 4 == 0) && aligned16(lp.out);
+        }
+    }
+    vst = vst && any_out;
+    const bool avec = (a.K % 4 == 0) && (a.ldx % 4 == 0) && aligned16(a.X);
+    const bool kfull = (a.K % BK == 0);
+    a.k_steps = round_up(a.K, BK) / KSTEP;
+    const int64_t g_tiles = ((int64_t)a.B + 4 * WM - 1) / (4 * WM);
+    a.n_wg = (a.F + BN - 1) / BN;
+    const int64_t grid = a.n_parts == 1 ? grid_for(g_tiles, a.n_wg) : (g_tiles + 3) / 4 * a.n_wg * 8;
+    if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: batch too large", who);
+    a.g_tiles = (int)g_tiles;
+    const bool fullt = (a.T == 32) && (a.B % (4 * WM) == 0);
+#define GGCN_LAUNCH(SC, AV, KF, FT, VS) \
+    hipLaunchKernelGGL((layer_fused_kernel<SC, AV, KF, FT, VS>), dim3((unsigned)grid), dim3(kThreads), 0, st, a)
+#define GGCN_PICK(SC)                                                                 \
+    do {                                                                              \
+        if (avec && kfull && fullt && vst) GGCN_LAUNCH(SC, true, true, true, true);   \
+        else if (avec && kfull && fullt) GGCN_LAUNCH(SC, true, true, true, false);    \
+        else if (avec && kfull && vst) GGCN_LAUNCH(SC, true, true, false, true);      \
+        else if (avec && kfull) GGCN_LAUNCH(SC, true, true, false, false);            \
+        else if (avec) GGCN_LAUNCH(SC, true, false, false, false);                    \
+        else GGCN_LAUNCH(SC, false, false, false, false);                             \
+    } while (0)
+    if (precision == GGCN_PREC_F16MX8) GGCN_PICK(1);
+    else GGCN_PICK(0);
+#undef GGCN_PICK
+#undef GGCN_LAUNCH
+    return check_launch(who);
+}
+
 }  // namespace
 
-#ifdef GGCN_LAB_TRACE
-extern "C" int ggcn_lab_trace_read(void *dst, size_t bytes)
-{
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ggcn_trace_buf), bytes, 0, hipMemcpyDeviceToHost);
-}
-#endif
+GGCN_TRACE_READER
 
 int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask, hipStream_t st)
 {
@@ -314,45 +437,45 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
 {
     if ((overlap_in == nullptr) != (overlap_out == nullptr))
         return fail(GGCN_EINVAL, "ggcn_layer_fused: overlap_in and overlap_out go together");
-    if (precision != GGCN_PREC_BF16X3 && precision != GGCN_PREC_F16MX8)
-        return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: precision %d (use bf16x3 or f16mx8)", precision);
-    if (!X || !wpack || !rowmask) return fail(GGCN_EINVAL, "ggcn_layer_fused: null input pointer");
-    if (B <= 0 || T <= 0 || K <= 0 || F <= 0)
-        return fail(GGCN_EINVAL, "ggcn_layer_fused: B=%d T=%d K=%d F=%d must be positive", B, T, K, F);
-    if (T > 32) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: T=%d > 32; use ggcn_linear + ggcn_aggregate", T);
-    if (!out && !pool_a && !pool_b) return fail(GGCN_EINVAL, "ggcn_layer_fused: no output requested");
-    if (ldx < K || (out && ldo < F)) return fail(GGCN_EINVAL, "ggcn_layer_fused: leading dimension too small");
-    if (out && (int64_t)T * ldo >= (int64_t)INT32_MAX)
-        return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: T*ldo does not fit 32-bit offsets");
-    if (!aligned16(wpack)) return fail(GGCN_EINVAL, "ggcn_layer_fused: wpack must be 16-byte aligned");
-    const bool avec = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
-    const bool kfull = (K % BK == 0);
-    const int k_steps = round_up(K, BK) / KSTEP;
-    const int64_t g_tiles = ((int64_t)B + 4 * WM - 1) / (4 * WM);
-    const int n_wg = (F + BN - 1) / BN;
-    const int64_t grid = grid_for(g_tiles, n_wg);
-    if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: batch too large");
-    const char *wp = static_cast<const char *>(wpack);
-    const bool fullt = (T == 32) && (B % (4 * WM) == 0);
-    const bool vst = out && (F % 4 == 0) && (ldo % 4 == 0) && aligned16(out);
-#define GGCN_LAUNCH(SC, AV, KF, FT, VS)                                                                                  \
-    hipLaunchKernelGGL((layer_fused_kernel<SC, AV, KF, FT, VS>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, \
-                       rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, (int)ldo, pool_a,            \
-                       pool_b, overlap_partial, overlap_in, overlap_out, (int)g_tiles, n_wg, k_steps)
-#define GGCN_PICK(SC)                                                           \
-    do {                                                                        \
-        if (avec && kfull && fullt && vst) GGCN_LAUNCH(SC, true, true, true, true);   \
-        else if (avec && kfull && fullt) GGCN_LAUNCH(SC, true, true, true, false);    \
-        else if (avec && kfull && vst) GGCN_LAUNCH(SC, true, true, false, true);      \
-        else if (avec && kfull) GGCN_LAUNCH(SC, true, true, false, false);            \
-        else if (avec) GGCN_LAUNCH(SC, true, false, false, false);                    \
-        else GGCN_LAUNCH(SC, false, false, false, false);                             \
-    } while (0)
-    if (precision == GGCN_PREC_F16MX8) GGCN_PICK(1);
-    else GGCN_PICK(0);
-#undef GGCN_PICK
-#undef GGCN_LAUNCH
-    return check_launch("ggcn_layer_fused");
+    if (out && ldo > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: ldo too large");
+    FusedArgs a = {};
+    a.X = X; a.ldx = ldx; a.rowmask = rowmask; a.ov_in = overlap_in; a.ov_out = overlap_out;
+    a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = 1;
+    a.part[0] = LayerPart{static_cast<const char *>(wpack), bias, nullptr, store_gate, pool_gate_a, pool_gate_b,
+                          out, pool_a, pool_b, overlap_partial, (int)ldo};
+    return launch_fused("ggcn_layer_fused", a, precision, st);
+}
+
+int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const uint32_t *rowmask,
+                const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
+                const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
+                float *x1, float *y1, float *pool_out, float *overlap_partial, int precision, hipStream_t st)
+{
+    if (!gate1 || !gate2) return fail(GGCN_EINVAL, "ggcn_block_fused: gate1 and gate2 are required");
+    if (!x1 || !y1) return fail(GGCN_EINVAL, "ggcn_block_fused: x1 and y1 are required");
+    if (!x_out && !pool_out) return fail(GGCN_EINVAL, "ggcn_block_fused: neither x nor its pool requested");
+    if ((gcn1 && ld1 > (int64_t)INT32_MAX) || (x_out && ld2 > (int64_t)INT32_MAX))
+        return fail(GGCN_EUNSUPPORTED, "ggcn_block_fused: leading dimension too large");
+    FusedArgs a = {};
+    a.X = X; a.ldx = ldx; a.rowmask = rowmask;
+    a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = 2;
+    // bert_amir5.py:626-636: gcn1 (ungated; optional here), x1 = max_t gcn1*gate1, y1 = max_t gcn1*gate2
+    a.part[0] = LayerPart{static_cast<const char *>(wpack1), bias1, nullptr, nullptr, gate1, gate2,
+                          gcn1, x1, y1, overlap_partial, (int)ld1};
+    // bert_amir5.py:639-640: x = gate2 * gc2(gcn1), out = max_t x.  A NULL mid bias (gc1 without bias) still
+    // needs the second aggregation: a vector of zeros cannot be conjured here, so the caller passes one.
+    if (!bias_mid) return fail(GGCN_EINVAL, "ggcn_block_fused: bias_mid (W2^T.b1, zeros when gc1 has no bias) is required");
+    a.part[1] = LayerPart{static_cast<const char *>(wpack12), bias2, bias_mid, gate2, gate2, nullptr,
+                          x_out, pool_out, nullptr, nullptr, (int)ld2};
+    return launch_fused("ggcn_block_fused", a, precision, st);
+}
+
+int overlap_reduce(const float *partials, int B, int F, float *xy, hipStream_t st)
+{
+    if (!partials || !xy) return fail(GGCN_EINVAL, "ggcn_overlap_reduce: null pointer");
+    if (B <= 0 || F <= 0) return fail(GGCN_EINVAL, "ggcn_overlap_reduce: B=%d F=%d must be positive", B, F);
+    hipLaunchKernelGGL(overlap_reduce_kernel, dim3(1), dim3(kRedThreads), 0, st, partials, B * ((F + 63) / 64), B, xy);
+    return check_launch("ggcn_overlap_reduce");
 }
 
 }  // namespace ggcn

@@ -1,0 +1,29 @@
+// Lab-only instrumentation for the matrix kernels (tools/lab.py builds with -DGGCN_LAB_TRACE).
+// In the product build every hook below is empty: nothing here changes a product kernel.
+#pragma once
+
+#ifdef GGCN_LAB_TRACE
+// timeline probe: per workgroup {block, HW_ID, XCC_ID, t_start, t_loop_begin, t_loop_end, t_end} in 10 ns ticks
+__device__ unsigned long long ggcn_trace_buf[8192 * 8];
+#define GGCN_TRACE(slot)                                                                                        \
+    do {                                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) ggcn_trace_buf[blockIdx.x * 8 + (slot)] = wall_clock64();   \
+    } while (0)
+#define GGCN_TRACE_IDS()                                                                                         \
+    do {                                                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                             \
+            ggcn_trace_buf[blockIdx.x * 8 + 0] = blockIdx.x;                                                     \
+            ggcn_trace_buf[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg(4 | (31 << 11));  /* HW_REG_HW_ID */  \
+            ggcn_trace_buf[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); /* HW_REG_XCC_ID */ \
+        }                                                                                                        \
+    } while (0)
+#define GGCN_TRACE_READER                                                                                \
+    extern "C" int ggcn_lab_trace_read(void *dst, size_t bytes)                                          \
+    {                                                                                                    \
+        return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ggcn_trace_buf), bytes, 0, hipMemcpyDeviceToHost); \
+    }
+#else
+#define GGCN_TRACE(slot) do { } while (0)
+#define GGCN_TRACE_IDS() do { } while (0)
+#define GGCN_TRACE_READER
+#endif

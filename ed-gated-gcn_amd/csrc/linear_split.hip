@@ -163,7 +163,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_split_kernel(
     else
         mx8::mainloop<ET, AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
 
-#ifndef GGCN_LAB_NO_STORE
     const bool full_rows = m0 + BM <= M;  // workgroup-uniform: the row guard only exists in the last tile
     if constexpr (VST) {
         static_assert(!VST || RN == 2, "the staged epilogue is written for 64 columns per wavefront");
@@ -218,13 +217,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_split_kernel(
             }
         }
     }
-#else
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < RN; ++j) asm volatile("" ::"v"(acc[i][j]));
-    if (M < 0) store_elem(Y, 0.f);
-#endif
 }
 
 template <int SCH, typename ET>

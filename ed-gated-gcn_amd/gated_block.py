@@ -9,9 +9,11 @@ Reference (BertAmir55; identical in BertAmir54 ``:512-531``)::
     xy = (x1 * y1).sum(1).mean()
     x = gate2 * self.gc2(gcn1, adj);  out = max_t(x)
 
-Here the gates stay ``[B,H]``; each layer is one linear + one aggregation launch that
-also applies the gate and the max over tokens, and the adjacency is converted to CSR
-once for both layers.
+Here the gates stay ``[B,H]`` and the adjacency is converted once for both layers.  Inference on
+graphs of <= 32 tokens runs the WHOLE block as one launch (``ggcn_block_fused``: no non-linearity sits
+between gc1 and gc2, so gc2(gc1(x)) is a product of x with the folded weight W1.W2 and gcn1 never
+touches HBM); otherwise each layer is one fused launch, or one linear + one aggregation launch that
+also applies the gate and the max over tokens.
 """
 import torch
 
@@ -32,12 +34,53 @@ def gate_overlap(x1, y1):
     return xy
 
 
-def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2):
+def _block_operands(gc1, gc2, lib, st):
+    """Operands of the one-launch block (``ggcn_block_fused``), rebuilt only when a parameter changes:
+
+    * packed ``W1`` (gc1's own image), packed ``W12 = W1 . W2`` and ``mid = W2^T . b1``.
+
+    ``bert_amir5.py:626,639`` feed gc2 with the UNGATED gcn1 and ``gcn.py:30-45`` applies no non-linearity,
+    so ``gc2(gc1(x)) = D.A.(D.A.(x.W12) + mid) + b2``.  W12 and mid come from the library's exact-fp32 MFMA
+    linear (a k-ordered fp32 FMA chain): they are parameters folded once per weight update, not activations."""
+    w1, w2, b1 = gc1.weight, gc2.weight, gc1.bias
+    prec = _capi.PREC[gc1.precision]
+    key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version, None if b1 is None else (b1.data_ptr(), b1._version),
+           w1.device, prec)
+    cached = getattr(gc2, "_block_ops", None)
+    if cached is None or cached[0] != key:
+        K, F1, F2 = gc1.in_features, gc1.out_features, gc2.out_features
+        dev = w1.device
+        w1c, w2c = w1.detach().contiguous(), w2.detach().contiguous()
+        w12 = torch.empty(K, F2, dtype=torch.float32, device=dev)
+        _capi.check(lib.ggcn_linear(_capi.ptr(w1c), F1, _capi.ptr(w2c), F2, None, _capi.ptr(w12), F2, K, F1, F2,
+                                    _capi.PREC["fp32"], st), "ggcn_linear(W1.W2)")
+        mid = torch.zeros(F2, dtype=torch.float32, device=dev)
+        if b1 is not None:
+            b1c = b1.detach().contiguous()
+            _capi.check(lib.ggcn_linear(_capi.ptr(b1c), F1, _capi.ptr(w2c), F2, None, _capi.ptr(mid), F2, 1, F1, F2,
+                                        _capi.PREC["fp32"], st), "ggcn_linear(b1.W2)")
+        pack12 = torch.empty(lib.ggcn_weight_pack_bytes(K, F2, prec), dtype=torch.uint8, device=dev)
+        _capi.check(lib.ggcn_weight_pack(_capi.ptr(w12), F2, K, F2, prec, 0, _capi.ptr(pack12), st), "ggcn_weight_pack(W12)")
+        cached = (key, pack12, mid)
+        gc2._block_ops = cached
+    return gc1._packed_weight(lib, st), cached[1], cached[2]
+
+
+def takes_block_path(x, csr, gc1, gc2):
+    """True when the inference block runs as ONE launch: both layers on the one-launch layer path with the
+    same arithmetic, and gc1's output width = gc2's (the reference's blocks are square, bert_amir5.py:559-560)."""
+    return (gc1.takes_fused_path(x, csr) and gc2.takes_fused_path(x, csr) and gc1.precision == gc2.precision
+            and gc1.out_features == gc2.in_features and gc1.out_features == gc2.out_features)
+
+
+def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=True):
     """x [B,T,H] fp32, adj dense [B,T,T] or BatchedCSR, gate1/gate2 [B,H], gc1/gc2 GraphConvolution.
 
-    Returns the tensors the reference block produces:
-    ``gcn1`` (ungated, feeds layer 2), ``x1``, ``y1``, ``xy``, ``x`` (gated layer-2 output), ``out``.
-    """
+    Returns the tensors the reference block produces: ``x1``, ``y1``, ``xy``, ``x`` (gated layer-2 output),
+    ``out``, and ``gcn1`` (the ungated layer-1 output).  Nothing downstream of ``bert_amir5.py:640`` reads
+    gcn1, so in inference it is only produced on request (``want_gcn1=True``; ``None`` otherwise) -- the
+    one-launch block never writes it to HBM unless asked.  Under autograd (training) the two layers run as
+    two launches and gcn1 is always returned."""
     if x.shape[0] == 0:   # empty batch: what the reference's ops give on empty tensors (the mean of nothing is nan)
         gc1._check(x)
         B, T, F = 0, x.shape[1], gc2.out_features
@@ -47,6 +90,40 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2):
                 "x": x.new_zeros((0, T, F)), "out": z2}
     csr = adj if isinstance(adj, BatchedCSR) else gc1._as_csr(adj, x)
     training = torch.is_grad_enabled() and (gc1._needs_grad(x, gate1, gate2) or gc2._needs_grad(x, gate2))
+    if not training and one_launch and takes_block_path(x, csr, gc1, gc2):
+        # ---- ONE launch for :626-640 (+ one 1-block launch that finishes :638) ----
+        gc1._check(x)
+        lib = _capi.load_library()
+        B, T, K = x.shape
+        F = gc2.out_features
+        dev = x.device
+        x2d = x.reshape(B * T, K)
+        if x2d.stride(1) != 1:
+            x2d = x2d.contiguous()
+        for name, g in (("gate1", gate1), ("gate2", gate2)):
+            if not (isinstance(g, torch.Tensor) and g.is_cuda and g.dtype == torch.float32
+                    and tuple(g.shape) == (B, F) and g.is_contiguous()):
+                raise RuntimeError("%s must be a contiguous float32 [B,F]=[%d,%d] GPU tensor" % (name, B, F))
+        with torch.cuda.device(dev):
+            st = _capi.stream_of(dev)
+            pack1, pack12, mid = _block_operands(gc1, gc2, lib, st)
+            gcn1 = torch.empty(B * T, F, dtype=torch.float32, device=dev) if want_gcn1 else None
+            xo = torch.empty(B * T, F, dtype=torch.float32, device=dev)
+            x1 = torch.empty(B, F, dtype=torch.float32, device=dev)
+            y1 = torch.empty(B, F, dtype=torch.float32, device=dev)
+            out = torch.empty(B, F, dtype=torch.float32, device=dev)
+            part = torch.empty(B, (F + 63) // 64, dtype=torch.float32, device=dev)
+            xy = torch.empty((), dtype=torch.float32, device=dev)
+            b1 = None if gc1.bias is None else gc1.bias.detach()
+            b2 = None if gc2.bias is None else gc2.bias.detach()
+            _capi.check(lib.ggcn_block_fused(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack1), _capi.ptr(pack12),
+                                             _capi.ptr(csr.rowmask), _capi.ptr(b1), _capi.ptr(mid), _capi.ptr(b2),
+                                             B, T, K, F, _capi.ptr(gate1), _capi.ptr(gate2), _capi.ptr(gcn1), F,
+                                             _capi.ptr(xo), F, _capi.ptr(x1), _capi.ptr(y1), _capi.ptr(out),
+                                             _capi.ptr(part), _capi.PREC[gc1.precision], st), "ggcn_block_fused")
+            _capi.check(lib.ggcn_overlap_reduce(_capi.ptr(part), B, F, _capi.ptr(xy), st), "ggcn_overlap_reduce")
+        return {"gcn1": None if gcn1 is None else gcn1.view(B, T, F), "x1": x1, "y1": y1, "xy": xy,
+                "x": xo.view(B, T, F), "out": out}
     if (not training and gc1.takes_fused_path(x, csr) and gc2.takes_fused_path(x, csr)
             and gc1.out_features == gc2.out_features):
         # two launches in all: layer 1 leaves its share of sum_f x1*y1 per (graph, 64 columns), layer 2's

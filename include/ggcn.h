@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 4
+#define GGCN_ABI_VERSION 5
 
 typedef void *ggcn_stream_t;
 
@@ -208,6 +208,31 @@ int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint3
                      float *out, int64_t ldo, float *pool_a, float *pool_b,
                      float *overlap_partial, const float *overlap_in, float *overlap_out,
                      int precision, ggcn_stream_t stream);
+
+/* ---- the whole gated block in one launch (graphs of <= 32 nodes, binary adjacency, inference) ----
+ * Replaces models/bert_amir5.py:626-640 -- gc1, both gates, both max-pools, gc2, its gate and pool -- with
+ * ONE launch that reads X once and never writes gcn1 unless asked to.  The reference feeds gc2 with the
+ * UNGATED gcn1 and applies no non-linearity between the layers (models/gcn.py:19 declares a Tanh that
+ * forward never calls; models/bert_amir5.py:626,639), so with D = diag(1/(rowsum(A)+1)):
+ *     gcn1 = D.A.X.W1 + b1
+ *     gcn2 = D.A.gcn1.W2 + b2 = D.A.( D.A.(X.W12) + bias_mid ) + b2,   W12 = W1.W2,  bias_mid = W2^T.b1
+ * wpack1 / wpack12: ggcn_weight_pack images of W1 [K,F] and W12 [K,F] for `precision`; the caller makes
+ * W12 and bias_mid once per weight update (ggcn_linear with GGCN_PREC_FP32: an exact fp32 product;
+ * bias_mid is a vector of F zeros when gc1 has no bias).  bias1 / bias2 may be NULL.
+ * Outputs: x1 = max_t gcn1*gate1, y1 = max_t gcn1*gate2 ([B,F], required), x_out = gate2*gcn2 [N, ld2]
+ * (or NULL), pool_out = max_t x ([B,F] or NULL), gcn1 [N, ld1] only when non-NULL (nothing downstream
+ * of the block reads it), overlap_partial (NULL or float[B*ceil(F/64)]) as in ggcn_layer_fused -- finish
+ * it with ggcn_overlap_reduce.  Same flop count as two ggcn_layer_fused launches; X is read once and the
+ * 4.N.F-byte write + read of gcn1 disappears.  Training keeps the two-launch path (autograd needs gcn1). */
+int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12,
+                     const uint32_t *rowmask, const float *bias1, const float *bias_mid, const float *bias2,
+                     int B, int T, int K, int F, const float *gate1, const float *gate2,
+                     float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
+                     float *x1, float *y1, float *pool_out, float *overlap_partial,
+                     int precision, ggcn_stream_t stream);
+/* models/bert_amir5.py:638 from the partials a ggcn_block_fused / ggcn_layer_fused launch left:
+ * *xy = mean_b sum_f x1*y1, fixed summation order (deterministic), one small launch. */
+int ggcn_overlap_reduce(const float *partials, int B, int F, float *xy, ggcn_stream_t stream);
 
 /* ---- gate-diversity regulariser --------------------------------------------
  * Replaces models/bert_amir5.py:638: *xy = mean_b sum_f x1[b,f]*y1[b,f].

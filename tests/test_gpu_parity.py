@@ -37,12 +37,21 @@ def pkg():
 # (precision, fused): the one-launch layer kernel exists for the two split-precision linears
 MODES = [("fp32", False), ("bf16x3", False), ("bf16x3", True), ("f16mx8", False), ("f16mx8", True)]
 MODE_IDS = ["fp32", "bf16x3-unfused", "bf16x3-fused", "f16mx8-unfused", "f16mx8-fused"]
+# block-level tests add the whole block as ONE launch (ggcn_block_fused: W1.W2 folded, gcn1 optional);
+# "fused" there means one launch per layer
+BLOCK_MODES = MODES + [("bf16x3", "block"), ("f16mx8", "block")]
+BLOCK_IDS = MODE_IDS + ["bf16x3-block", "f16mx8-block"]
+
+
+def _block(pkg, x, adj, g1, g2, gc1, gc2, fused, want_gcn1=True):
+    """The block through the path named by `fused` (False / True: per-layer launches; "block": one launch)."""
+    return pkg.gated_gcn_block(x, adj, g1, g2, gc1, gc2, want_gcn1=want_gcn1, one_launch=(fused == "block"))
 
 
 def _layer(pkg, dev, w, b, precision, fused=True):
     m = pkg.GraphConvolution(w.shape[0], w.shape[1], opt=None, bias=b is not None).to(dev)
     m.precision = precision
-    m.fused = fused
+    m.fused = bool(fused)
     with torch.no_grad():
         m.weight.copy_(torch.from_numpy(w))
         if b is not None:
@@ -132,14 +141,14 @@ def test_layer_golden_sweep(pkg, dev, golden_dir, precision, fused):
                                    err_msg="%s (%s)" % (desc, precision))
 
 
-@pytest.mark.parametrize("precision,fused", MODES, ids=MODE_IDS)
+@pytest.mark.parametrize("precision,fused", BLOCK_MODES, ids=BLOCK_IDS)
 def test_gated_block_golden_bertamir55(pkg, dev, golden_dir, precision, fused):
     g = np.load(os.path.join(golden_dir, "amir55_block.npz"))
     t = lambda k: torch.from_numpy(g[k]).to(dev)
     gc1 = _layer(pkg, dev, g["p_gc1.weight"], g["p_gc1.bias"], precision, fused)
     gc2 = _layer(pkg, dev, g["p_gc2.weight"], g["p_gc2.bias"], precision, fused)
     with torch.no_grad():
-        r = pkg.gated_gcn_block(t("lstm_out"), t("adj"), t("gate1"), t("gate2"), gc1, gc2)
+        r = _block(pkg, t("lstm_out"), t("adj"), t("gate1"), t("gate2"), gc1, gc2, fused)
     tol = TOL[precision]
     np.testing.assert_allclose(r["gcn1"].cpu().numpy(), g["gcn1"], rtol=0, atol=tol)
     np.testing.assert_allclose(r["x"].cpu().numpy(), g["gate2"][:, None, :] * g["gc2_out"], rtol=0, atol=tol)
@@ -153,7 +162,7 @@ def _oracle_block(x, adj, g1, g2, w1, b1, w2, b2):
     return ref_dense.gated_block(t(x), t(adj), t(g1), t(g2), t(w1), t(b1), t(w2), t(b2))
 
 
-@pytest.mark.parametrize("precision,fused", MODES, ids=MODE_IDS)
+@pytest.mark.parametrize("precision,fused", BLOCK_MODES, ids=BLOCK_IDS)
 @pytest.mark.parametrize("B,T,H,padded", [(64, 32, 768, False), (16, 31, 256, True), (3, 100, 200, True),
                                           (2, 231, 64, True), (1, 1, 8, False), (7, 5, 300, True),
                                           (9, 32, 100, False), (5, 17, 34, True)])
@@ -171,7 +180,7 @@ def test_gated_block_vs_oracle(pkg, dev, precision, fused, B, T, H, padded):
     gc1, gc2 = _layer(pkg, dev, w1, b1, precision, fused), _layer(pkg, dev, w2, b2, precision, fused)
     td = lambda a: torch.from_numpy(a).to(dev)
     with torch.no_grad():
-        r = pkg.gated_gcn_block(td(x), td(adj), td(g1), td(g2), gc1, gc2)
+        r = _block(pkg, td(x), td(adj), td(g1), td(g2), gc1, gc2, fused)
     tol = TOL[precision]
     for k in ("gcn1", "x1", "y1", "x", "out"):
         np.testing.assert_allclose(r[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=tol, err_msg=k)
@@ -267,20 +276,19 @@ def config2(pkg, dev):
     return dict(B=B, T=T, H=H, adj=adj, csr=csr, x=x, g1=g1, g2=g2, w1=w1, b1=b1, w2=w2, b2=b2)
 
 
-@pytest.mark.parametrize("precision,fused", MODES, ids=MODE_IDS)
+@pytest.mark.parametrize("precision,fused", BLOCK_MODES, ids=BLOCK_IDS)
 def test_config2_full_size_properties(pkg, dev, config2, precision, fused):
     c = config2
     gc1 = _layer(pkg, dev, c["w1"], c["b1"], precision, fused)
     gc2 = _layer(pkg, dev, c["w2"], c["b2"], precision, fused)
     with torch.no_grad():
-        r = pkg.gated_gcn_block(c["x"], c["csr"], c["g1"], c["g2"], gc1, gc2)
+        r = _block(pkg, c["x"], c["csr"], c["g1"], c["g2"], gc1, gc2, fused)
         # (1) graphs are independent: a 64-graph slice run alone gives the same numbers
         sl = slice(1000, 1064)
         from ed_gated_gcn_amd import synth
         rp, ci, _ = synth.csr_from_dense_host(c["adj"][sl])
         sub = pkg.BatchedCSR.from_arrays(rp, ci, 64, c["T"], dev)
-        rs = pkg.gated_gcn_block(c["x"][sl].contiguous(), sub, c["g1"][sl].contiguous(),
-                                 c["g2"][sl].contiguous(), gc1, gc2)
+        rs = _block(pkg, c["x"][sl].contiguous(), sub, c["g1"][sl].contiguous(), c["g2"][sl].contiguous(), gc1, gc2, fused)
     for k in ("gcn1", "x", "out", "x1", "y1"):
         assert torch.equal(r[k][sl], rs[k]), k
     # (2) the slice equals the CPU oracle
@@ -475,7 +483,8 @@ def test_gated_block_backward_vs_oracle_autograd(pkg, dev, precision, fused):
         _grad_close(gv, lv.grad, name, rel=5e-4)
     # forward values under autograd equal the inference path
     with torch.no_grad():
-        ri = pkg.gated_gcn_block(xg.detach(), t(adj).to(dev), g1g.detach(), g2g.detach(), gc1, gc2)
+        ri = pkg.gated_gcn_block(xg.detach(), t(adj).to(dev), g1g.detach(), g2g.detach(), gc1, gc2, want_gcn1=True,
+                                 one_launch=False)
     for k in ("gcn1", "x", "out", "x1", "y1"):
         assert torch.max(torch.abs(ri[k] - r[k].detach())).item() <= 4e-5, k
 
@@ -575,7 +584,8 @@ def test_hipgraph_capture_replays_bit_identically(pkg, dev):
         ref = pkg.gated_gcn_block(x2, csr, g1, g2, gc1, gc2)
     got = cap(x2, g1, g2)
     torch.cuda.synchronize()
-    for k in ("gcn1", "x", "out", "x1", "y1", "xy"):
+    assert ref["gcn1"] is None and got["gcn1"] is None    # the one-launch block writes gcn1 only on request
+    for k in ("x", "out", "x1", "y1", "xy"):
         assert torch.equal(ref[k], got[k]), k
 
 
@@ -637,9 +647,10 @@ def test_subword_pool_dense_rows_and_backward(pkg, dev):
         pkg.subword_pool(torch.from_numpy(a).to(dev), torch.from_numpy(x).to(dev)[:, :5])  # shape mismatch
 
 
+@pytest.mark.parametrize("one_launch", [False, True], ids=["two-launches", "one-launch"])
 @pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
 @pytest.mark.parametrize("B,T,H", [(5, 7, 96), (9, 32, 72), (130, 31, 256), (3, 1, 8)])
-def test_regulariser_folded_into_the_layer_launches(pkg, dev, B, T, H, precision):
+def test_regulariser_folded_into_the_layer_launches(pkg, dev, B, T, H, precision, one_launch):
     """bert_amir5.py:638 without launches of its own (partials from layer 1's epilogue, reduced by layer
     2's launch) == ggcn_gate_overlap on the same x1, y1 == the oracle; and it is deterministic."""
     from ed_gated_gcn_amd import synth
@@ -652,8 +663,8 @@ def test_regulariser_folded_into_the_layer_launches(pkg, dev, B, T, H, precision
     (w1, b1), (w2, b2) = synth.layer_params(H, H, seed=1), synth.layer_params(H, H, seed=2)
     l1, l2 = _layer(pkg, dev, w1, b1, precision), _layer(pkg, dev, w2, b2, precision)
     with torch.no_grad():
-        r = pkg.gated_gcn_block(x.to(dev), adj.to(dev), g1.to(dev), g2.to(dev), l1, l2)
-        again = pkg.gated_gcn_block(x.to(dev), adj.to(dev), g1.to(dev), g2.to(dev), l1, l2)
+        r = pkg.gated_gcn_block(x.to(dev), adj.to(dev), g1.to(dev), g2.to(dev), l1, l2, one_launch=one_launch)
+        again = pkg.gated_gcn_block(x.to(dev), adj.to(dev), g1.to(dev), g2.to(dev), l1, l2, one_launch=one_launch)
         standalone = gate_overlap(r["x1"], r["y1"])
     ref = ref_dense.gated_block(x, adj.float(), g1, g2, torch.from_numpy(w1), torch.from_numpy(b1),
                                 torch.from_numpy(w2), torch.from_numpy(b2))
@@ -771,3 +782,46 @@ def test_zero_gates_pool_to_signed_zero_not_minus_inf(pkg, dev, precision, fused
         assert np.isfinite(got).all()
         np.testing.assert_allclose(got, want.numpy(), rtol=0, atol=50 * TOL[precision])   # |y| ~ 50
     assert (pa.cpu().numpy()[:, ::3] == 0).all() and (pb.cpu().numpy()[::2] == 0).all()
+
+
+# ---------------------------------------------------------------- the block as ONE launch (ggcn_block_fused)
+@pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
+@pytest.mark.parametrize("B,T,H,bias", [(64, 32, 768, True), (33, 31, 256, True), (6, 7, 96, False), (130, 32, 300, True)])
+def test_one_launch_block_equals_two_launches(pkg, dev, B, T, H, bias, precision):
+    """gc2(gc1(x)) through the folded weight W1.W2 (one launch, gcn1 never stored) against the two-launch
+    path and the oracle; gcn1 on request is the same tensor layer 1 alone produces; weights that change are
+    re-folded; a second call is bit-identical."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(B * H)
+    adj = torch.from_numpy(synth.dependency_batch(B, T, min(4.0, T), seed=5, lengths=rng.integers(2, T + 1, size=B))).to(dev)
+    x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32)).to(dev)
+    g1 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32))).to(dev)
+    g2 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32))).to(dev)
+    (w1, b1), (w2, b2) = synth.layer_params(H, H, seed=1), synth.layer_params(H, H, seed=2)
+    l1, l2 = _layer(pkg, dev, w1, b1 if bias else None, precision), _layer(pkg, dev, w2, b2 if bias else None, precision)
+    with torch.no_grad():
+        one = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2)
+        one_g = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, want_gcn1=True)
+        two = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, one_launch=False)
+    assert one["gcn1"] is None
+    tol = TOL[precision]
+    for k in ("x1", "y1", "x", "out"):
+        assert torch.equal(one[k], one_g[k]), k
+        assert float((one[k] - two[k]).abs().max()) <= tol, k
+    assert torch.equal(one["x1"], two["x1"]) and torch.equal(one["y1"], two["y1"])   # layer 1 is the same arithmetic
+    assert torch.equal(one_g["gcn1"], two["gcn1"])
+    assert abs(float(one["xy"]) - float(two["xy"])) <= 2e-6 * max(1.0, abs(float(two["xy"])))
+    assert torch.equal(one["out"], one["x"].max(dim=1)[0])
+    t = torch.from_numpy
+    zeros = np.zeros(H, np.float32)
+    ref = ref_dense.gated_block(x.cpu(), adj.cpu().float(), g1.cpu(), g2.cpu(), t(w1), t(b1 if bias else zeros),
+                                t(w2), t(b2 if bias else zeros))
+    for k in ("x1", "y1", "x", "out"):
+        np.testing.assert_allclose(one[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=tol, err_msg=k)
+    # a weight update invalidates the folded operands
+    with torch.no_grad():
+        l2.weight.mul_(0.5)
+        upd = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2)
+        upd2 = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, one_launch=False)
+    assert float((upd["x"] - upd2["x"]).abs().max()) <= tol
+    assert float((upd["x"] - one["x"]).abs().max()) > 10 * tol

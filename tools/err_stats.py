@@ -25,15 +25,17 @@ ref = block64(x.double(), t(adj).double(), g1.double(), g2.double(), t(w1).doubl
               t(w2).double(), t(b2).double())
 f32 = ref_dense.gated_block(x, t(adj).float(), g1, g2, t(w1), t(b1), t(w2), t(b2))
 print("%-22s %s" % ("torch-cpu fp32", "  ".join("%s %.2e" % (k, float((f32[k].double() - ref[k]).abs().max())) for k in ("gcn1", "x", "out"))))
-for prec, fused in (("fp32", False), ("bf16x3", False), ("bf16x3", True), ("f16mx8", False), ("f16mx8", True)):
+for prec, fused in (("fp32", False), ("bf16x3", False), ("bf16x3", True), ("bf16x3", "block"), ("f16mx8", False),
+                    ("f16mx8", True), ("f16mx8", "block")):
     ls = []
     for w, b in ((w1, b1), (w2, b2)):
-        m = pkg.GraphConvolution(H, H, None).to(dev); m.precision = prec; m.fused = fused
+        m = pkg.GraphConvolution(H, H, None).to(dev); m.precision = prec; m.fused = bool(fused)
         with torch.no_grad():
             m.weight.copy_(t(w)); m.bias.copy_(t(b))
         ls.append(m)
     with torch.no_grad():
-        r = pkg.gated_gcn_block(x.to(dev), t(adj).to(dev), g1.to(dev), g2.to(dev), *ls)
-    print("%-22s %s" % (prec + ("-fused" if fused else ""), "  ".join(
+        r = pkg.gated_gcn_block(x.to(dev), t(adj).to(dev), g1.to(dev), g2.to(dev), *ls, want_gcn1=True,
+                                one_launch=(fused == "block"))
+    print("%-22s %s" % (prec + ("-block" if fused == "block" else "-fused" if fused else ""), "  ".join(
         "%s max %.2e rms %.2e" % (k, float((r[k].cpu().double() - ref[k]).abs().max()),
                                   float((r[k].cpu().double() - ref[k]).pow(2).mean().sqrt())) for k in ("gcn1", "x", "out"))))

@@ -19,7 +19,7 @@ for (B, T, H) in ((256, 31, 256), (4096, 32, 768)):
         ref = pkg.gated_gcn_block(x, csr, g1, g2, *ls)
     got = cap(x, g1, g2)
     torch.cuda.synchronize()
-    assert all(torch.equal(ref[k], got[k]) for k in ("gcn1", "x", "out", "x1", "y1")), "graph replay differs"
+    assert all(torch.equal(ref[k], got[k]) for k in ("x", "out", "x1", "y1")), "graph replay differs"
     def wall(fn, n=200):
         for _ in range(10): fn()
         torch.cuda.synchronize(); t0 = time.perf_counter()

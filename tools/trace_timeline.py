@@ -12,6 +12,7 @@ from ed_gated_gcn_amd import _capi, synth
 
 variant = sys.argv[1] if len(sys.argv) > 1 else "trace"
 NOOUT = "noout" in sys.argv
+BLOCK = "block" in sys.argv     # the whole gated block as one launch (ggcn_block_fused): 6 column tiles per row block
 prec = 2 if (len(sys.argv) > 2 and sys.argv[2] == "mx8") or len(sys.argv) <= 2 else 0
 lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_lab", "libggcn_%s.so" % variant))
 for fn, (res, args) in _capi.PROTOTYPES.items():
@@ -30,15 +31,23 @@ out = torch.empty(B * T, H, device=dev); pa = torch.empty(B, H, device=dev); pb 
 p = _capi.ptr
 pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H, prec), dtype=torch.uint8, device=dev)
 assert lib.ggcn_weight_pack(p(w), H, H, H, prec, 0, p(pack), None) == 0
+pack12 = torch.empty_like(pack)
+assert lib.ggcn_weight_pack(p(w.t().contiguous()), H, H, H, prec, 0, p(pack12), None) == 0   # timing only: any weights do
+part = torch.empty(B, 12, device=dev)
 def run():
+    if BLOCK:
+        rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack12), p(csr.rowmask), p(b), p(b), p(b), B, T, H, H, p(g1), p(g2),
+                                  None, H, p(out), H, p(pa), p(pb), p(pa), p(part), prec, None)
+        assert rc == 0
+        return
     rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2), None if NOOUT else p(out), H,
                               p(pa), p(pb), None, None, None, prec, None)
     assert rc == 0
-for _ in range(5):
+for _ in range(int(os.environ.get('TRACE_WARMUP', '300'))):   # the chip needs ~0.1 s of load to settle
     run()
 torch.cuda.synchronize()
 run(); torch.cuda.synchronize()
-n = 3072
+n = 6144 if BLOCK else 3072
 buf = np.zeros(n * 8, dtype=np.uint64)
 lib.ggcn_lab_trace_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert lib.ggcn_lab_trace_read(buf.ctypes.data, buf.nbytes) == 0
@@ -50,6 +59,11 @@ print("kernel span %.1f us; blocks %d" % (end.max(), n))
 print("prologue  (start->loop)   median %.2f us  p10 %.2f p90 %.2f" % tuple(np.percentile(lb - start, [50, 10, 90])))
 print("main loop                 median %.2f us  p10 %.2f p90 %.2f" % tuple(np.percentile(le - lb, [50, 10, 90])))
 print("epilogue  (loop->end)     median %.2f us  p10 %.2f p90 %.2f" % tuple(np.percentile(end - le, [50, 10, 90])))
+if BLOCK:
+    second = (tr[:, 0].astype(np.int64) & 7) >= 4
+    for name, sel in (("layer-1 tiles", ~second), ("layer-2 tiles", second)):
+        print("  %s: main loop median %.2f us, epilogue median %.2f us (p90 %.2f), whole %.2f" % (
+            name, np.median((le - lb)[sel]), np.median((end - le)[sel]), np.percentile((end - le)[sel], 90), np.median((end - start)[sel])))
 print("HW_ID bits that vary: %s" % bin(int(np.bitwise_or.reduce(hw ^ hw[0]))))
 cu_key = (xcc << 32) | (hw & 0xFF00)       # cu_id[11:8], sh_id[12], se_id[15:13]; bits 16-19 are the workgroup slot
 cus = collections.defaultdict(list)
@@ -91,7 +105,7 @@ print(" ".join("%d" % h for h in hist))
 # siblings = the 3 column tiles of one row block (tile_of_block: xcd = id & 7, slot = id >> 3)
 n_wg = 3
 ids = tr[:, 0].astype(np.int64)
-m_tile = (ids >> 3) // n_wg * 8 + (ids & 7)
+m_tile = ((ids >> 3) // n_wg * 4 + (ids & 3)) * 2 + ((ids & 7) >> 2) if BLOCK else (ids >> 3) // n_wg * 8 + (ids & 7)
 same_xcc = 0; spread = []; xcc_of_id_ok = 0
 by_tile = collections.defaultdict(list)
 for i in range(n):
@@ -102,7 +116,7 @@ for t, members in by_tile.items():
         same_xcc += int(len({int(xcc[i]) for i in members}) == 1)
         spread.append(max(start[i] for i in members) - min(start[i] for i in members))
 print("XCC_ID == id & 7 for %d of %d blocks" % (xcc_of_id_ok, n))
-print("row blocks whose 3 column tiles ran on one XCD: %d of %d" % (same_xcc, len(by_tile)))
+print("row blocks whose column tiles all ran on one XCD: %d of %d" % (same_xcc, len(by_tile)))
 print("start-time spread inside a sibling group: median %.2f us  p90 %.2f  max %.2f" % (np.median(spread), np.percentile(spread, 90), max(spread)))
 spread_le = [max(le[i] for i in m) - min(le[i] for i in m) for m in by_tile.values() if len(m) == n_wg]
 print("loop-end spread inside a sibling group:   median %.2f us  p90 %.2f  max %.2f" % (np.median(spread_le), np.percentile(spread_le, 90), max(spread_le)))
