@@ -132,6 +132,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
         // SAME part -- four XCDs take the W1 tiles, four the W12 tiles -- so that each XCD's 4 MiB L2 holds one
         // weight image for the whole launch.  (Both images side by side, 3.7-5 MB, do not fit: with the column
         // tiles of both parts mixed on every XCD the main loop ran 17 % slower, W streaming from beyond L2.)
+        // (Handing the W1 group a few of the W12 row blocks to even out the ~4 % costlier W12 tiles was
+        // measured: no gain at 4096 graphs, +12 % time at 512 where it adds a round.)
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         second = xcd >= 4;
         g_tile = (slot / a.n_wg) * 4 + (xcd & 3);
@@ -190,22 +192,31 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
     GGCN_TRACE(5);
 
     const int c = lane & 31, h = lane >> 5;
-    // bias and the gates of the 4 graphs x 2 column tiles: all loads issued together, one latency
+    // bias and the gates of the 4 graphs x 2 column tiles: all loads issued together, one latency.  The loads
+    // are unconditional (a NULL operand reads X[0] instead and is replaced by its neutral value where it is
+    // USED): a branch around each load makes hipcc wait for the loads inside the issuing block, in front of
+    // the first graph's adjacency MFMAs instead of behind them.
     float vb[RN], vmid[RN], vsg[4][RN], vga[4][RN], vgb[4][RN];
     bool col_ok[RN];
+    {
+        const float *dummy = a.X;
+        const float *pb = bias ? bias : dummy, *pm = mid ? mid : dummy;
+        const float *psg = store_gate ? store_gate : dummy, *pga = pool_gate_a ? pool_gate_a : dummy,
+                    *pgb = pool_gate_b ? pool_gate_b : dummy;
 #pragma unroll
-    for (int j = 0; j < RN; ++j) {
-        const int gn = (nt0 + j) * NT + c;
-        col_ok[j] = gn < F;
-        const int gnc = col_ok[j] ? gn : 0;
-        vb[j] = bias ? bias[gnc] : 0.0f;
-        vmid[j] = mid ? mid[gnc] : 0.0f;
+        for (int j = 0; j < RN; ++j) {
+            const int gn = (nt0 + j) * NT + c;
+            col_ok[j] = gn < F;
+            const int gnc = col_ok[j] ? gn : 0;
+            vb[j] = pb[bias ? gnc : 0];
+            vmid[j] = pm[mid ? gnc : 0];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t at = (int64_t)(g0 + i < B ? g0 + i : 0) * F + gnc;
-            vsg[i][j] = store_gate ? store_gate[at] : 1.0f;
-            vga[i][j] = pool_gate_a ? pool_gate_a[at] : 1.0f;
-            vgb[i][j] = pool_gate_b ? pool_gate_b[at] : 1.0f;
+            for (int i = 0; i < 4; ++i) {
+                const int64_t at = (int64_t)(g0 + i < B ? g0 + i : 0) * F + gnc;
+                vsg[i][j] = psg[store_gate ? at : 0];
+                vga[i][j] = pga[pool_gate_a ? at : 0];
+                vgb[i][j] = pgb[pool_gate_b ? at : 0];
+            }
         }
     }
     const int lane_off = 4 * h * ldo + c;  // this lane's element inside a (graph, column tile) block
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
             if (mid) {  // workgroup-uniform: the block's second layer through W12 = W1.W2 (header)
                 f32x16 u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) u[r] = y[r] * rinv[r] + vmid[j];          // D.A.(X.W12) + c
+                for (int r = 0; r < 16; ++r) u[r] = y[r] * rinv[r] + vmid[j];          // D.A.(X.W12) + c (mid != NULL here)
                 y = adj_times(afv, u);                                                 // gcn.py:41 of layer 2
             }
 
@@ -260,11 +271,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
             // track max and min of y once, apply both pool gates at the end (bert_amir5.py:635-640)
             float vmax = -INFINITY, vmin = INFINITY;
             float *tile = out ? out + ((int64_t)g * T) * ldo + (nt0 + j) * NT : nullptr;  // wave-uniform
-            const float sg = vsg[i][j];
+            const float sg = store_gate ? vsg[i][j] : 1.0f;
+            const float bj = bias ? vb[j] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
-                const float v = y[r] * rinv[r] + vb[j];   // gcn.py:41,43
+                const float v = y[r] * rinv[r] + bj;      // gcn.py:41,43
                 if (vst) {
                     // staged for the 16-byte row stores below; columns of the rows with bit 2 set are
                     // swapped between the two 32-column halves so that h = 0 / 1 hit different banks
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
             vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
             vmin = fminf(vmin, __shfl_xor(vmin, 32));
             if (h == 0 && col_ok[j]) {
-                const float ga = vga[i][j], gb = vgb[i][j];
+                const float ga = pool_gate_a ? vga[i][j] : 1.0f, gb = pool_gate_b ? vgb[i][j] : 1.0f;
                 const float pa = ga * (ga >= 0.0f ? vmax : vmin), pb = gb * (gb >= 0.0f ? vmax : vmin);
                 if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
                 if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
@@ -308,6 +320,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        if (i == 0) GGCN_TRACE(7);
     }
     GGCN_TRACE(6);
 }

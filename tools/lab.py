@@ -3,6 +3,7 @@
 each, interleaved in ONE process (cdna guide §5.4 rule 24).  Development tool, not product code.
 
   python tools/lab.py build  name1:-DFLAG_A name2:"-DFLAG_B -DFLAG_C" ...   (CPU box: cross-compiles)
+  python tools/lab.py build  old@<git-rev>[:flags]                            (the csrc/ of that revision)
   python tools/lab.py time linear|aggregate|block [names...]                 (GPU box)
 """
 import ctypes
@@ -23,9 +24,18 @@ def build(specs):
     procs = []
     for spec in specs:
         name, _, flags = spec.partition(":")
+        name, _, rev = name.partition("@")
+        src_dir, these = CSRC, srcs
+        if rev:   # sources of another revision, extracted beside the lab libraries
+            src_dir = os.path.join(LAB, "src_" + name, "ed-gated-gcn_amd", "csrc")
+            os.makedirs(os.path.join(LAB, "src_" + name), exist_ok=True)
+            tar = subprocess.run(["git", "-C", ROOT, "archive", rev, "ed-gated-gcn_amd/csrc", "include"], check=True,
+                                 capture_output=True).stdout
+            subprocess.run(["tar", "-x", "-C", os.path.join(LAB, "src_" + name)], input=tar, check=True)
+            these = [f for f in sorted(os.listdir(src_dir)) if f.endswith(".hip")]
         out = os.path.join(LAB, "libggcn_%s.so" % name)
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-o", out] + flags.split() + [os.path.join(CSRC, s) for s in srcs]
+               "-o", out] + flags.split() + [os.path.join(src_dir, s) for s in these]
         procs.append((name, subprocess.Popen(cmd)))
     for name, p in procs:
         if p.wait():
@@ -38,7 +48,7 @@ def time_variants(what, names):
     import ed_gated_gcn_amd as pkg
     from ed_gated_gcn_amd import _capi, synth
     dev = torch.device("cuda:0")
-    B, T, H = 4096, 32, 768
+    B, T, H = int(os.environ.get("LAB_GRAPHS", "4096")), 32, 768
     N = B * T
     adj = synth.dependency_batch(B, T, 4.0)
     rowptr, colidx, _ = synth.csr_from_dense_host(adj)
@@ -54,6 +64,7 @@ def time_variants(what, names):
     y = torch.empty(N, H, device=dev)
     out = torch.empty(N, H, device=dev)
     pa, pb = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+    pc, part = torch.empty(B, H, device=dev), torch.empty(B, (H + 63) // 64, device=dev)
     if not names:
         names = sorted(f[len("libggcn_"):-3] for f in os.listdir(LAB) if f.endswith(".so"))
     libs = {}
@@ -88,6 +99,9 @@ def time_variants(what, names):
                                       p(out), H, p(pa), p(pb), None, None, None, prec, st)
             rc = rc or lib.ggcn_layer_fused(p(out), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, p(g2), p(g2), None,
                                             p(y), H, p(pa), None, None, None, None, prec, st)
+        elif what == "blockfused":    # the whole gated block as one launch (timing: W12 := the same image)
+            rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack), p(csr.rowmask), p(b), p(b), p(b), B, T, H, H, p(g1), p(g2),
+                                      None, H, p(out), H, p(pa), p(pb), p(pc), p(part), prec, st)
         elif what == "fused":
             rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
                                       p(out), H, p(pa), p(pb), None, None, None, prec, st)

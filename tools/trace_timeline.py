@@ -59,6 +59,8 @@ print("kernel span %.1f us; blocks %d" % (end.max(), n))
 print("prologue  (start->loop)   median %.2f us  p10 %.2f p90 %.2f" % tuple(np.percentile(lb - start, [50, 10, 90])))
 print("main loop                 median %.2f us  p10 %.2f p90 %.2f" % tuple(np.percentile(le - lb, [50, 10, 90])))
 print("epilogue  (loop->end)     median %.2f us  p10 %.2f p90 %.2f" % tuple(np.percentile(end - le, [50, 10, 90])))
+g0e = (tr[:, 7] - t0).astype(np.float64) / 100.0
+print("epilogue: gate loads + first graph median %.2f us; each later graph %.2f us" % (np.median(g0e - le), np.median(end - g0e) / 3))
 if BLOCK:
     second = (tr[:, 0].astype(np.int64) & 7) >= 4
     for name, sel in (("layer-1 tiles", ~second), ("layer-2 tiles", second)):
