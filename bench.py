@@ -9,10 +9,12 @@ synthetic dependency graphs already resident in HBM.  Workload = BASELINE.json c
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config 4          # BASELINE.json configs[3]: 256 x 512-token graphs, hidden 1024, fp16 features
 
-N > 1: one process per GPU, every rank owns its own 4096-graph batch (weak scaling; graphs are
-independent, so the data path has no exchange) and the per-shard pooled outputs [B,H] are
-all-gathered over RCCL/xGMI each step -- the path's only collective.
+N > 1 (BASELINE.json configs[2]): the SAME 4096-graph batch is sharded over the ranks -- contiguous graph
+ranges balanced by nnz, weights replicated; graphs are independent, so the data path has no exchange -- and
+the per-shard pooled outputs out[B_r, H] are all-gathered over RCCL/xGMI each step, the path's only
+collective; "scaling": "strong".  `--scaling weak` gives every rank its own 4096-graph batch.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -29,6 +31,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (spec, no sparsity)
 MFMA_F32_PEAK_TF = 157.3     # f32-input MFMA peak
+SURVEY_8D_BYTES_PER_LAYER = 822873092   # 2*4*N*H + 4(N+1) + 4E + 4*B*H + 4H^2 + 4H
+
+ISSUE_NOTE = {
+    "bf16x3": "the bf16x3 linear issues 3 bf16 MFMA flops per algorithmic flop, so its ceiling on this peak is 1/3 "
+              "(833 TFLOP/s)",
+    "f16mx8": "the f16mx8 linear spends 128 matrix-pipe cycles per 32x32x32 block (64 fp16 + 64 block-scaled fp8) "
+              "where plain bf16 spends 64, so its ceiling on this peak is 1/2 (1250 TFLOP/s)",
+    "fp32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+}
+DTYPE_NOTE = {"fp32": "f32", "bf16x3": "f32 (bf16x3 MFMA split, fp32 accumulate)",
+              "f16mx8": "f32 (fp16 MFMA + block-scaled fp8 correction MFMA, fp32 accumulate)"}
 
 
 def parse():
@@ -36,48 +49,67 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+                    help="2: BASELINE.json configs[1]/[2] (4096 x 32 tokens, hidden 768, fp32, 2 layers; the headline); "
+                         "4: configs[3] (256 x 512 tokens, degree 6, hidden 1024, fp16 features, 1 gated layer)")
     ap.add_argument("--precondition", type=int, default=-1,
                     help="untimed steps run before the warm-up: the chip needs ~0.1 s of load to settle (measured: "
                          "the first ~60 steps after an idle period run 4.5 %% slower, DESIGN.md 5); the W warm-up "
                          "steps and the K timed steps follow as the contract says.  -1 (default): adaptive -- "
                          "windows of 50 steps until two consecutive windows agree within 1 %% (at least 150, at most "
                          "2000 steps)")
-    ap.add_argument("--graphs", type=int, default=4096, help="graphs per GPU (config 2: 4096)")
-    ap.add_argument("--tokens", type=int, default=32)
-    ap.add_argument("--hidden", type=int, default=768)
-    ap.add_argument("--degree", type=float, default=4.0)
+    ap.add_argument("--graphs", type=int, default=None, help="graphs in the batch (config 2: 4096, config 4: 256)")
+    ap.add_argument("--tokens", type=int, default=None)
+    ap.add_argument("--hidden", type=int, default=None)
+    ap.add_argument("--degree", type=float, default=None)
     ap.add_argument("--precision", default=os.environ.get("GGCN_PRECISION", "f16mx8"),
                     choices=["f16mx8", "bf16x3", "fp32"],
-                    help="arithmetic of the dense linear; all three meet the 1e-4 parity gate (tests/test_gpu_parity.py)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --graphs per GPU; strong: --graphs in total, sharded (BASELINE configs[2])")
-    ap.add_argument("--unfused", action="store_true", help="force linear + aggregate (2 launches per layer)")
-    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="2: consecutive steps alternate between two HIP streams, so the tail and the launch gap of "
-                         "one step's kernels are filled by the next step's (about +4 %% edges/s, DESIGN.md 5); the "
-                         "per-launch figures of `roofline` are then taken from a single-stream pass after the timed region")
+                    help="arithmetic of the dense linear of the TIMED run; all three meet the 1e-4 parity gate "
+                         "(tests/test_gpu_parity.py) and the other two are timed beside it (alt_precisions)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default, BASELINE configs[2]): --graphs in total, sharded over the GPUs; "
+                         "weak: --graphs per GPU")
+    ap.add_argument("--path", default="block", choices=["block", "layers", "unfused"],
+                    help="block: the whole gated block as one launch (default); layers: one launch per layer; "
+                         "unfused: linear + aggregate (2 launches per layer)")
+    ap.add_argument("--capture", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a hipGraph (auto: when N > 1, where a shard's kernels are short enough "
+                         "for the host launch path to show)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the alt_precisions / accuracy legs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to "
                     "rehearse the N>1 code path on a one-GPU box together with --same-device")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--cpu-graphs", type=int, default=4096, help="sample size of the CPU baseline")
-    return ap.parse_args()
+    ap.add_argument("--cpu-graphs", type=int, default=None, help="sample size of the CPU baseline")
+    a = ap.parse_args()
+    d = {2: (4096, 32, 768, 4.0, 4096), 4: (256, 512, 1024, 6.0, 16)}[a.config]
+    a.graphs = a.graphs or d[0]
+    a.tokens = a.tokens or d[1]
+    a.hidden = a.hidden or d[2]
+    a.degree = a.degree or d[3]
+    a.cpu_graphs = a.cpu_graphs or d[4]
+    return a
 
 
-def cpu_baseline(x, adj, g1, g2, w1, b1, w2, b2, n_graphs):
+def cpu_baseline(x, adj, g1, g2, w1, b1, w2, b2, n_graphs, one_layer):
     """The reference's dense algorithm (oracle/ref_dense.py, bit-equal to the imported reference in
     the build container) on this host's cores: 1 warm-up + median of 5 forwards."""
     import torch
     from oracle import ref_dense
     avail = len(os.sched_getaffinity(0))
     n = min(n_graphs, x.shape[0])
-    xs, adjs, g1s, g2s = x[:n], adj[:n].float(), g1[:n], g2[:n]
+    xs, adjs, g1s, g2s = x[:n].float(), adj[:n].float(), g1[:n], g2[:n]
     nnz = int((adj[:n] != 0).sum())
 
     def once():
         t0 = time.perf_counter()
         with torch.no_grad():
-            ref_dense.gated_block(xs, adjs, g1s, g2s, w1, b1, w2, b2)
+            if one_layer:   # config 4: gcn.py:30-45 + both gates and pools of bert_amir5.py:627-636
+                y = ref_dense.graph_convolution(xs, adjs, w1, b1)
+                torch.max(y * g1s[:, None, :], 1)
+                torch.max(y * g2s[:, None, :], 1)
+            else:
+                ref_dense.gated_block(xs, adjs, g1s, g2s, w1, b1, w2, b2)
         return time.perf_counter() - t0
 
     # torch-CPU slows down when oversubscribed on many-core hosts: probe a few thread counts
@@ -93,9 +125,48 @@ def cpu_baseline(x, adj, g1, g2, w1, b1, w2, b2, n_graphs):
     times = [once() for _ in range(5)]
     t = statistics.median(times)
     return {"value": nnz / t, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": "%d of the %d graphs (T=%d, H=%d, 2 layers, dense adj, torch-CPU fp32), "
+            "sample": "%d of the %d graphs (T=%d, H=%d, %s, dense adj, torch-CPU fp32), "
                       "threads chosen from {16,32,64,all=%d} by a probe, median of 5, %.3f s per forward"
-                      % (n, x.shape[0], x.shape[1], x.shape[2], avail, t)}
+                      % (n, x.shape[0], x.shape[1], x.shape[2], "1 gated layer" if one_layer else "2 layers", avail, t)}
+
+
+def block_float64(x, adj, g1, g2, w1, b1, w2, b2, one_layer):
+    """float64 evaluation of models/gcn.py:30-45 + models/bert_amir5.py:621-640 on a small slice: the yardstick of
+    `max_abs_err` (plain torch-CPU double arithmetic written out here; nothing is imported for it)."""
+    import torch
+    a = adj.double()
+    den = a.sum(2, keepdim=True) + 1
+    x, g1, g2, w1, b1, w2, b2 = (t.double() for t in (x, g1, g2, w1, b1, w2, b2))
+    gcn1 = (a @ (x @ w1)) / den + b1
+    r = {"x1": (gcn1 * g1[:, None, :]).max(1)[0], "y1": (gcn1 * g2[:, None, :]).max(1)[0]}
+    if not one_layer:
+        x2 = g2[:, None, :] * ((a @ (gcn1 @ w2)) / den + b2)
+        r.update({"x": x2, "out": x2.max(1)[0]})
+    return r
+
+
+def capture_steps(torch, dev, forward):
+    """Two hipGraph copies of one step with their own output buffers: step i's all-gather may still be reading
+    copy i % 2 while step i+1 replays the other one."""
+    graphs = []
+    for _ in range(2):
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                forward()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(g):
+            r = forward()
+        graphs.append((g, r))
+    return graphs
+
+
+def percentiles(v):
+    v = sorted(v)
+    pick = lambda q: v[min(len(v) - 1, int(round(q * (len(v) - 1))))]
+    return {"median": statistics.median(v), "p10": pick(0.10), "p90": pick(0.90), "min": v[0], "max": v[-1]}
 
 
 def main():
@@ -105,14 +176,13 @@ def main():
     import torch.distributed as dist
 
     import ed_gated_gcn_amd as pkg
-    from ed_gated_gcn_amd import synth
+    from ed_gated_gcn_amd import _capi, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
     dev = torch.device("cuda", 0 if args.same_device else local)
     torch.cuda.set_device(dev)
@@ -122,66 +192,100 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    pkg.load_library()
-    B_total = args.graphs * world if args.scaling == "weak" else args.graphs
-    B = args.graphs if args.scaling == "weak" else (args.graphs // world)
-    if args.scaling == "strong" and args.graphs % world:
-        raise SystemExit("--scaling strong needs --graphs divisible by the number of GPUs")
+    lib = pkg.load_library()
+    one_layer = args.config == 4
+    half = args.config == 4
     T, H = args.tokens, args.hidden
 
-    # ---- synthetic batch of this rank, resident in HBM before timing --------
-    adj_np = synth.dependency_batch(B, T, args.degree, seed=synth.SEED + rank)
+    # ---- the batch, generated identically on every rank; this rank's shard goes to HBM ----
+    if args.scaling == "strong":
+        B_total = args.graphs
+        if B_total < world:
+            raise SystemExit("cannot shard %d graphs over %d GPUs" % (B_total, world))
+        adj_all = synth.dependency_batch(B_total, T, args.degree, seed=synth.SEED)
+        parts = shard.partition_graphs(adj_all.reshape(B_total, -1).sum(1, dtype=np.int64), world)
+        lo, hi = parts[rank]
+        counts = [h - l for l, h in parts]
+        seed_x = synth.SEED
+    else:
+        B_total = args.graphs * world
+        adj_all = synth.dependency_batch(args.graphs, T, args.degree, seed=synth.SEED + rank)
+        lo, hi = 0, args.graphs
+        counts = [args.graphs] * world
+        seed_x = synth.SEED + rank
+    B = hi - lo
+    adj_np = adj_all[lo:hi]
     rowptr, colidx, _ = synth.csr_from_dense_host(adj_np)
     nnz = int(rowptr[-1])
     csr = pkg.BatchedCSR.from_arrays(rowptr, colidx, B, T, dev)
-    gen = torch.Generator().manual_seed(synth.SEED + rank)
-    x_cpu = torch.randn(B, T, H, generator=gen)
-    g1_cpu = torch.sigmoid(torch.randn(B, H, generator=gen))
-    g2_cpu = torch.sigmoid(torch.randn(B, H, generator=gen))
+    gen = torch.Generator().manual_seed(seed_x)
+    nb = adj_all.shape[0]
+    x_all = torch.randn(nb, T, H, generator=gen)
+    g1_all = torch.sigmoid(torch.randn(nb, H, generator=gen))
+    g2_all = torch.sigmoid(torch.randn(nb, H, generator=gen))
+    x_cpu, g1_cpu, g2_cpu = x_all[lo:hi], g1_all[lo:hi], g2_all[lo:hi]
+    if half:
+        x_cpu = x_cpu.half()
     w1, b1 = synth.layer_params(H, H, seed=1)
     w2, b2 = synth.layer_params(H, H, seed=2)
     x, g1, g2 = x_cpu.to(dev), g1_cpu.to(dev), g2_cpu.to(dev)
     layers = []
     for w, b in ((w1, b1), (w2, b2)):
         m = pkg.GraphConvolution(H, H, opt=None).to(dev)
-        m.precision = args.precision
-        m.fused = not args.unfused
         with torch.no_grad():
             m.weight.copy_(torch.from_numpy(w))
             m.bias.copy_(torch.from_numpy(b))
         layers.append(m.eval())
     gc1, gc2 = layers
+
+    def set_mode(precision, path):
+        for m in layers:
+            m.precision = precision
+            m.fused = path != "unfused"
+
+    def forward(xx=None, cc=None, a1=None, a2=None, path=None):
+        """One pass of the hot path; returns the dict of outputs (config 4: one gated layer)."""
+        xx, cc = (x if xx is None else xx), (csr if cc is None else cc)
+        a1, a2 = (g1 if a1 is None else a1), (g2 if a2 is None else a2)
+        if one_layer:
+            _, pa, pb = gc1.forward_gated(xx, cc, pool_gate_a=a1, pool_gate_b=a2, want_out=True,
+                                          want_pool_a=True, want_pool_b=True)
+            return {"x1": pa, "y1": pb, "out": pa}
+        return pkg.gated_gcn_block(xx, cc, a1, a2, gc1, gc2, one_launch=((path or args.path) == "block"))
+
     # the path's only collective: all-gather of the per-shard pooled outputs [B_r, H], launched
     # asynchronously so step i's gather (RCCL's stream, xGMI) overlaps step i+1's kernels
-    from ed_gated_gcn_amd import shard
-    gather = shard.PooledGather([B] * world, H, dev) if world > 1 else None
+    gather = shard.PooledGather(counts, H, dev) if world > 1 else None
     pending = []
-
-    side = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    capture = args.capture == "on" or (args.capture == "auto" and world > 1)
+    set_mode(args.precision, args.path)
+    graphs = None
+    capture_note = None
+    if capture:
+        try:
+            graphs = capture_steps(torch, dev, forward)
+        except Exception as e:   # noqa: BLE001 -- a refused capture must not cost the run: eager launches instead
+            graphs, capture_note = None, "hipGraph capture refused (%s: %s); eager launches" % (type(e).__name__, str(e)[:200])
+            torch.cuda.synchronize(dev)
     counter = [0]
 
     def step():
         with torch.no_grad():
-            if side is None:
-                r = pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2)
-            else:   # independent batches: step i runs on stream i % 2 (the inputs are read-only)
-                with torch.cuda.stream(side[counter[0] % args.streams]):
-                    r = pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2)
-                    if world > 1:
-                        if pending:
-                            gather.finish(pending.pop())
-                        pending.append(gather.start(r["out"]))
-                counter[0] += 1
-                return r
+            if graphs is None:
+                r = forward()
+            else:
+                g, r = graphs[counter[0] & 1]
+                g.replay()
+            counter[0] += 1
             if world > 1:
-                if pending:
-                    gather.finish(pending.pop())      # step i-1's gather: done or nearly done
+                while len(pending) > 1:
+                    gather.finish(pending.pop(0))     # step i-2's gather (its buffers are about to be reused)
                 pending.append(gather.start(r["out"]))
         return r
 
     def sync_all():
         while pending:
-            gather.finish(pending.pop())
+            gather.finish(pending.pop(0))
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -212,39 +316,66 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    # HIP events around every layer launch INSIDE the timed region (torch's current stream is the
-    # stream every ggcn_* call is enqueued on): roofline.achieved uses their mean
-    layer_events = []
 
-    def with_events(fn):
-        def wrapped(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides.  HIP events on the launch stream
+    # (torch's current stream IS the stream every ggcn_* call is enqueued on) bracket every step and, in eager
+    # mode, every launch of the dominant kernel (ggcn_block_fused / ggcn_layer_fused / ggcn_linear*).
+    # The event objects are created AND recorded once before the timed region: the first record of an event
+    # creates the underlying hipEvent, which costs the host tens of microseconds -- enough to leave the GPU idle
+    # between the short steps of a small shard.
+    def make_events(n):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        for e in evs:
+            e.record()
+        return evs
+    # An event record is a barrier packet on the stream (~2-3 us of GPU time each): with a short step (a small
+    # shard) only every 4th step carries the per-launch events and the step events bracket 4 steps at a time.
+    sparse = last is not None and (last / 50) < 300e-6 if args.precondition < 0 else (world > 1)
+    ev_stride = 4 if sparse else 1
+    kernel_events = {}
+    kernel_pool = make_events(8 * (args.steps // ev_stride + 1)) if graphs is None else []
+    sampling = [False]
+
+    def with_events(name):
+        fn = getattr(lib, name)
+
+        def wrapped(*a):
+            if not sampling[0]:
+                return fn(*a)
+            e0, e1 = kernel_pool.pop(), kernel_pool.pop()
             e0.record()
-            r = fn(*a, **k)
+            rc = fn(*a)
             e1.record()
-            layer_events.append((e0, e1))
-            return r
-        return wrapped
-    plain = (gc1.forward_gated, gc2.forward_gated)
-    gc1.forward_gated, gc2.forward_gated = with_events(plain[0]), with_events(plain[1])
+            kernel_events.setdefault(name, []).append((e0, e1))
+            return rc
+        return fn, wrapped
+    hooked = {}
+    step_pool = make_events(args.steps + 1)
+    torch.cuda.synchronize(dev)
+    if graphs is None:
+        for name in ("ggcn_block_fused", "ggcn_layer_fused", "ggcn_linear", "ggcn_linear_h", "ggcn_aggregate",
+                     "ggcn_aggregate_h"):
+            hooked[name], w = with_events(name)
+            setattr(lib, name, w)
+    sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_pool[0].record()
+    marks = [0]
+    for i in range(args.steps):
+        sampling[0] = (i % ev_stride) == 0
         step()
+        if (i + 1) % ev_stride == 0 or i + 1 == args.steps:
+            step_pool[i + 1].record()
+            marks.append(i + 1)
+    sampling[0] = False
     sync_all()
     elapsed = time.perf_counter() - t0
-    gc1.forward_gated, gc2.forward_gated = plain
-    t_layer_in_loop = statistics.mean(a.elapsed_time(b) for a, b in layer_events) * 1e-3   # seconds per layer launch
-    if side is not None:
-        # two steps in flight: a launch's events also span the other stream's kernels, so the per-launch
-        # time comes from a short single-stream pass over the same inputs
-        side, layer_events = None, []
-        gc1.forward_gated, gc2.forward_gated = with_events(plain[0]), with_events(plain[1])
-        for _ in range(max(10, min(args.steps, 50))):
-            with torch.no_grad():
-                pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2)
-        torch.cuda.synchronize(dev)
-        gc1.forward_gated, gc2.forward_gated = plain
-        t_layer_in_loop = statistics.mean(a.elapsed_time(b) for a, b in layer_events) * 1e-3
+    for name, fn in hooked.items():
+        setattr(lib, name, fn)
+    # per-step time of every bracketed group of steps (1 step, or ev_stride steps averaged)
+    step_events = [(step_pool[a], step_pool[b], b - a) for a, b in zip(marks[:-1], marks[1:])]
+    step_us = [a.elapsed_time(b) * 1e3 / n for a, b, n in step_events]
+    kern_us = {k: [a.elapsed_time(b) * 1e3 for a, b in v] for k, v in kernel_events.items()}
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -256,107 +387,152 @@ def main():
         nnz_total = nnz
     ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- per-kernel durations: HIP events on the launch stream (torch's current stream IS the
-    # stream every ggcn_* call is enqueued on), same inputs, right after the timed region ------
-    def time_kernel(fn, n):
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-        for a, b in evs:
-            a.record()
-            fn()
-            b.record()
-        torch.cuda.synchronize(dev)
-        return statistics.mean(a.elapsed_time(b) for a, b in evs) * 1e-3  # seconds
-
-    n_prof = max(10, min(args.steps, 50))
-    from ed_gated_gcn_amd import _capi
-    lib = pkg.load_library()
+    # ---- roofline of the dominant kernel (this rank's shard) ----
     N = B * T
-    x2d = x.view(B * T, H)
-    layer_bytes = synth.algorithmic_bytes_per_layer(B, T, H, nnz, n_gates=2)   # SURVEY 8d, layer-1 form
-    fwd_bytes = 2 * synth.algorithmic_bytes_per_layer(B, T, H, nnz)
-    lin_flops = 2.0 * N * H * H                       # algorithmic flops of gcn.py:34 per launch
+    s_el = 2 if half else 4
+    layer_bytes = synth.algorithmic_bytes_per_layer(B, T, H, nnz, n_gates=1, s=s_el)   # SURVEY 8d formula
+    n_layers = 1 if one_layer else 2
+    fwd_bytes = n_layers * layer_bytes
+    lin_flops = 2.0 * N * H * H                       # algorithmic flops of gcn.py:34 per layer
     agg_flops = 2.0 * nnz * H                         # gcn.py:41 on the non-zeros
     lin_peak = MFMA_F32_PEAK_TF if args.precision == "fp32" else MFMA_BF16_PEAK_TF
-    fused_path = gc1.fused and args.precision in ("bf16x3", "f16mx8") and csr.rowmask is not None and csr.is_binary
-    issue_note = {"bf16x3": "the bf16x3 linear issues 3 bf16 MFMA flops per algorithmic flop, so its ceiling on this "
-                            "peak is 1/3 (833 TFLOP/s)",
-                  "f16mx8": "the f16mx8 linear spends 128 matrix-pipe cycles per 32x32x32 block (64 fp16 + 64 "
-                            "block-scaled fp8) where plain bf16 spends 64, so its ceiling on this peak is 1/2 "
-                            "(1250 TFLOP/s)"}.get(args.precision, "")
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch, if recorded
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch, recorded separately
     measured = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    traffic_note = ("traffic = HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, separate passes) "
+                    "recorded in profiles/traffic.json for this kernel and workload; a constant of that profile run, "
+                    "not re-measured by this run")
     kernels = {}
-    if fused_path:
-        t_fused = t_layer_in_loop   # one kernel per layer launch: measured over the timed region itself
-        tf = (lin_flops + agg_flops) / t_fused / 1e12
-        traffic = measured.get("layer_fused_kernel:" + args.precision, measured.get("layer_fused_kernel"))
-        roofline = {"kernel": "layer_fused_kernel", "bound": "mfma", "achieved": tf, "peak": lin_peak,
-                    "unit": "TFLOP/s", "frac": tf / lin_peak, "traffic": traffic, "avg_launch_us": t_fused * 1e6,
-                    "algorithmic_flops_per_launch": lin_flops + agg_flops,
-                    "algorithmic_bytes_per_launch": layer_bytes,
-                    "hbm_GBps": layer_bytes / t_fused / 1e9, "hbm_frac": layer_bytes / t_fused / 1e9 / HBM_PEAK_GBS,
-                    "note": "achieved = algorithmic (2*N*K*F + 2*nnz*F) flops / launch; " + issue_note}
-        kernels["layer_fused"] = {"avg_launch_us": t_fused * 1e6, "algorithmic_tflops": tf, "launches_per_step": 2}
-    else:
-        with torch.no_grad():
-            hidden = gc1.linear(x2d)
-            t_lin = time_kernel(lambda: gc1.linear(x2d), n_prof)
-        out = torch.empty(B * T, H, device=dev)
-        pa = torch.empty(B, H, device=dev)
-        pb = torch.empty(B, H, device=dev)
+    for k, v in kern_us.items():
+        kernels[k] = dict(percentiles(v), unit="us", launches_timed=len(v),
+                          launches_per_step=len(v) / len(range(0, args.steps, ev_stride)))
+    if not kern_us:       # hipGraph replay: the per-launch events cannot be recorded; time the kernels once, eagerly
+        pass
 
-        def agg_once():   # aggregation alone, layer-1 form, through the C ABI
-            _capi.check(lib.ggcn_aggregate(_capi.ptr(hidden), H, _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx),
-                                           _capi.ptr(csr.vals), _capi.ptr(gc1.bias.detach()), B, T, H, None,
-                                           _capi.ptr(g1), _capi.ptr(g2), _capi.ptr(out), H, _capi.ptr(pa),
-                                           _capi.ptr(pb), _capi.stream_of(dev)), "ggcn_aggregate")
-        agg_once()
-        t_agg = time_kernel(agg_once, n_prof)
-        agg_bytes = layer_bytes - 4 * H * H
-        lin_tf = lin_flops / t_lin / 1e12
-        if t_lin >= t_agg:
-            roofline = {"kernel": "linear_fp32_kernel" if args.precision == "fp32" else "linear_split_kernel (%s)" % args.precision,
-                        "bound": "mfma", "achieved": lin_tf,
-                        "peak": lin_peak, "unit": "TFLOP/s", "frac": lin_tf / lin_peak,
-                        "traffic": measured.get("linear_split_kernel:" + args.precision), "avg_launch_us": t_lin * 1e6}
-        else:
-            gbs = agg_bytes / t_agg / 1e9
-            roofline = {"kernel": "aggregate_rows", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": measured.get("aggregate_rows"),
-                        "avg_launch_us": t_agg * 1e6}
-        kernels["linear"] = {"avg_launch_us": t_lin * 1e6, "algorithmic_tflops": lin_tf, "launches_per_step": 2}
-        kernels["aggregate"] = {"avg_launch_us": t_agg * 1e6, "algorithmic_GBps": agg_bytes / t_agg / 1e9,
-                                "hbm_frac": agg_bytes / t_agg / 1e9 / HBM_PEAK_GBS, "launches_per_step": 2}
+    def mfma_line(kernel, key, t_us, flops, nbytes, launches_note):
+        tf = flops / (t_us * 1e-6) / 1e12
+        return {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": lin_peak, "unit": "TFLOP/s",
+                "frac": tf / lin_peak, "traffic": measured.get(key), "avg_launch_us": t_us,
+                "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
+                "hbm_GBps": nbytes / (t_us * 1e-6) / 1e9, "hbm_frac": nbytes / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "note": launches_note + "; achieved = algorithmic flops / launch; " + ISSUE_NOTE[args.precision]
+                        + "; " + traffic_note}
+
+    roofline = None
+    if "ggcn_block_fused" in kern_us:
+        t = statistics.mean(kern_us["ggcn_block_fused"])
+        roofline = mfma_line("layer_fused_kernel (block form: both layers of the block in one launch)",
+                             "block_fused_kernel:" + args.precision, t, 2 * (lin_flops + agg_flops), fwd_bytes,
+                             "one launch per step = 2 layers: 2 x (2*N*K*F + 2*nnz*F) flops, 2 x SURVEY 8(d) bytes")
+    elif "ggcn_layer_fused" in kern_us:
+        t = statistics.mean(kern_us["ggcn_layer_fused"])
+        roofline = mfma_line("layer_fused_kernel", "layer_fused_kernel:" + args.precision, t, lin_flops + agg_flops,
+                             layer_bytes, "one launch per layer")
+    else:
+        lin_key = "ggcn_linear_h" if "ggcn_linear_h" in kern_us else "ggcn_linear"
+        agg_key = "ggcn_aggregate_h" if "ggcn_aggregate_h" in kern_us else "ggcn_aggregate"
+        if lin_key in kern_us and agg_key in kern_us:
+            t_lin, t_agg = statistics.mean(kern_us[lin_key]), statistics.mean(kern_us[agg_key])
+            if t_lin >= t_agg:
+                roofline = mfma_line("linear_fp32_kernel" if args.precision == "fp32" else
+                                     "linear_split_kernel (%s)" % args.precision,
+                                     "linear_split_kernel:" + args.precision, t_lin, lin_flops,
+                                     2 * s_el * N * H + 4 * H * H, "the dense linear of one layer")
+            else:
+                agg_bytes = layer_bytes - 4 * H * H
+                gbs = agg_bytes / (t_agg * 1e-6) / 1e9
+                roofline = {"kernel": "aggregate_rows", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": measured.get("aggregate_rows"),
+                            "avg_launch_us": t_agg, "algorithmic_bytes_per_launch": agg_bytes, "note": traffic_note}
+    if roofline is None:   # captured replay: whole-step figure from the per-step events
+        t = statistics.mean(step_us)
+        roofline = mfma_line("hipGraph replay of the step (%s path)" % args.path, "none", t,
+                             n_layers * (lin_flops + agg_flops), fwd_bytes,
+                             "per-launch events are not available under graph replay: whole step of this rank's shard")
+
+    # ---- other precisions on the same inputs + accuracy of each against float64 (rank 0's shard) ----
+    alt = None
+    if not args.no_alt:
+        alt = {}
+        ns = min(64, B) if not one_layer else min(4, B)
+        sub_adj = torch.from_numpy(adj_np[:ns])
+        rp_s, ci_s, _ = synth.csr_from_dense_host(adj_np[:ns])
+        csr_s = pkg.BatchedCSR.from_arrays(rp_s, ci_s, ns, T, dev)
+        t_ = torch.from_numpy
+        ref64 = block_float64(x_cpu[:ns].float(), sub_adj, g1_cpu[:ns], g2_cpu[:ns], t_(w1), t_(b1), t_(w2), t_(b2),
+                              one_layer)
+        xs, g1s, g2s = x[:ns].contiguous(), g1[:ns].contiguous(), g2[:ns].contiguous()
+        precs = ["f16mx8", "bf16x3"] if half else ["f16mx8", "bf16x3", "fp32"]
+        for prec in precs:
+            set_mode(prec, args.path)
+            with torch.no_grad():
+                rs = forward(xs, csr_s, g1s, g2s)
+                err = max(float((rs[k].double().cpu() - ref64[k]).abs().max()) for k in ref64)
+                n_alt = 10 if prec == "fp32" else 30
+                for _ in range(5):
+                    forward()
+                torch.cuda.synchronize(dev)
+                ev = []
+                for _ in range(n_alt):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    forward()
+                    e1.record()
+                    ev.append((e0, e1))
+                torch.cuda.synchronize(dev)
+            ms = statistics.median(a.elapsed_time(b) for a, b in ev)
+            alt[prec] = {"ms_per_step": ms, "edges_per_sec": nnz / (ms * 1e-3), "max_abs_err_vs_float64": err,
+                         "steps": n_alt, "timed": "median of per-step HIP events, eager, this rank's shard"}
+        set_mode(args.precision, args.path)
 
     result = None
     if rank == 0:
         value = nnz_total * args.steps / elapsed
+        per_step = percentiles(step_us)
+        workload = ("BASELINE.json configs[1]%s: %d graphs x %d tokens, avg degree %g (nnz %d incl. self loops), "
+                    "hidden %d, 2 gated-GCN layers, fp32 in/out" % (" sharded = configs[2]" if world > 1 and
+                    args.scaling == "strong" else "", B_total, T, args.degree, nnz_total, H)) if not one_layer else \
+                   ("BASELINE.json configs[3]: %d graphs x %d tokens, avg degree %g (nnz %d incl. self loops), hidden %d, "
+                    "fp16 features (fp32 accumulate), 1 gated-GCN layer with both gates and pools" %
+                    (B_total, T, args.degree, nnz_total, H))
+        path_note = {"block": "one launch for the block (ggcn_block_fused) + a 1-workgroup reduce for xy",
+                     "layers": "one launch per layer (ggcn_layer_fused)",
+                     "unfused": "linear + aggregate (2 launches per layer)"}[args.path]
+        if one_layer or not (gc1.fused and args.precision != "fp32" and csr.rowmask is not None):
+            path_note = "linear + aggregate (2 launches per layer)"
+        total_fwd_bytes = (2 * SURVEY_8D_BYTES_PER_LAYER if (args.config == 2 and B_total == 4096 and T == 32 and H == 768
+                                                              and nnz_total == 524288) else
+                           n_layers * synth.algorithmic_bytes_per_layer(B_total, T, H, nnz_total, n_gates=1, s=s_el))
         result = {
             "metric": "gated_gcn_forward_edges_per_sec", "value": value, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3 MFMA split, fp32 accumulate)",
-                      "f16mx8": "f32 (fp16 MFMA + block-scaled fp8 correction MFMA, fp32 accumulate)"}[args.precision],
+            "dtype": DTYPE_NOTE[args.precision] if not half else
+                     "f16 features, " + DTYPE_NOTE[args.precision].split("(")[-1].rstrip(")"),
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: %d graphs/GPU x %d tokens, avg degree %g "
-                                   "(nnz %d incl. self loops), hidden %d, 2 gated-GCN layers, fp32 in/out"
-                                   % (B, T, args.degree, nnz, H),
-                       "graphs_total": B_total, "precision": args.precision,
-                       "path": "fused (1 launch/layer)" if fused_path else "linear + aggregate (2 launches/layer)",
-                       "streams": args.streams, "precondition_steps": n_pre,
-                       "collective": "all_gather(out[B,H])" if world > 1 else "none"},
-            "edge_layers_per_sec": 2 * value,
-            "forward_algorithmic_bytes": fwd_bytes,
-            "forward_hbm_GBps": fwd_bytes * world / (elapsed / args.steps) / 1e9,
-            "forward_hbm_frac": fwd_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "config": {"workload": workload, "graphs_total": B_total, "graphs_per_gpu": counts,
+                       "precision": args.precision, "path": path_note, "hipgraph_replay": bool(graphs), "capture_note": capture_note,
+                       "precondition_steps": n_pre,
+                       "collective": "all_gather(out[B_r,H]) per step, async (RCCL)" if world > 1 else "none"},
+            "step_us": dict(per_step, events_every_n_steps=ev_stride,
+                            note="HIP events on the launch stream of rank 0 bracketing every step (or every 4 steps, "
+                                 "averaged, when a step is short); median, p10, p90 over the K timed steps; "
+                                 "ms_per_step is wall time / K, max over ranks"),
+            "edge_layers_per_sec": n_layers * value,
+            "forward_algorithmic_bytes": total_fwd_bytes,
+            "forward_hbm_GBps": total_fwd_bytes / (elapsed / args.steps) / 1e9,
+            "forward_hbm_frac": total_fwd_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roofline,
             "kernels": kernels,
         }
+        if alt is not None:
+            result["alt_precisions"] = alt
+            result["max_abs_err"] = {"precision": args.precision, "value": alt[args.precision]["max_abs_err_vs_float64"],
+                                     "against": "float64 evaluation of the reference formulas on the first %d graphs of the "
+                                                "timed inputs (x1, y1, x, out); parity gate 1e-4" % (min(64, B) if not one_layer else min(4, B))}
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only: other ranks would idle at the barrier
-            t = torch.from_numpy
-            result["cpu_baseline"] = cpu_baseline(x_cpu, t(adj_np), g1_cpu, g2_cpu, t(w1), t(b1), t(w2), t(b2),
-                                                  args.cpu_graphs)
+            t_ = torch.from_numpy
+            result["cpu_baseline"] = cpu_baseline(x_cpu, t_(adj_np), g1_cpu, g2_cpu, t_(w1), t_(b1), t_(w2), t_(b2),
+                                                  args.cpu_graphs, one_layer)
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
         print(json.dumps(result), flush=True)
     if world > 1:

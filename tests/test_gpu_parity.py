@@ -825,3 +825,83 @@ def test_one_launch_block_equals_two_launches(pkg, dev, B, T, H, bias, precision
         upd2 = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, one_launch=False)
     assert float((upd["x"] - upd2["x"]).abs().max()) <= tol
     assert float((upd["x"] - one["x"]).abs().max()) > 10 * tol
+
+
+# ---------------------------------------------------------------- N > 1 product path on one device
+def _shard_worker(rank, world, port, ret):
+    import traceback
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    try:
+        import torch.distributed as dist
+        import ed_gated_gcn_amd as pkg
+        from ed_gated_gcn_amd import shard, synth
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            dev = torch.device("cuda:0")
+            B, T, H = 37, 32, 256
+            rng = np.random.default_rng(5)
+            adj = synth.dependency_batch(B, T, 4.0, seed=3, lengths=rng.integers(3, T + 1, size=B))
+            x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32))
+            g1 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32)))
+            g2 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32)))
+            parts = shard.partition_graphs(adj.reshape(B, -1).sum(1), world)
+            lo, hi = parts[rank]
+            counts = [h - l for l, h in parts]
+            ls = []
+            for s in (1, 2):
+                w, b = synth.layer_params(H, H, seed=s)
+                m = pkg.GraphConvolution(H, H, None).to(dev)
+                with torch.no_grad():
+                    m.weight.copy_(torch.from_numpy(w)); m.bias.copy_(torch.from_numpy(b))
+                ls.append(m.eval())
+            rp, ci, _ = synth.csr_from_dense_host(adj)
+            lrp, lci = shard.shard_csr_host(rp, ci, T, lo, hi)
+            csr = pkg.BatchedCSR.from_arrays(lrp, lci, hi - lo, T, dev)
+            gather = shard.PooledGather(counts, H, dev)
+            outs = []
+            with torch.no_grad():
+                for k in range(3):      # three steps in flight over the two slots, like bench.py's loop
+                    r = pkg.gated_gcn_block((x[lo:hi] * (k + 1)).to(dev), csr, g1[lo:hi].to(dev), g2[lo:hi].to(dev), *ls)
+                    outs.append(gather.start(r["out"]))
+                got = [gather.finish(h).cpu().clone() for h in outs]
+                if rank == 0:           # the unsharded product path on the same device
+                    full = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
+                    want = [pkg.gated_gcn_block((x * (k + 1)).to(dev), full, g1.to(dev), g2.to(dev), *ls)["out"].cpu()
+                            for k in range(3)]
+                    for k in range(3):
+                        assert torch.equal(got[k], want[k]), "step %d: sharded != unsharded" % k
+            ret.put((rank, "ok", None))
+        finally:
+            dist.destroy_process_group()
+    except BaseException:   # noqa: B902
+        ret.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+def test_two_rank_sharded_block_same_device(pkg, dev):
+    """BASELINE configs[2] in small: two processes (gloo rendezvous, both on cuda:0) run the HIP block on their
+    nnz-balanced shards and all-gather the pooled outputs; graphs are independent, so the result equals the
+    unsharded block bit for bit.  Uneven shards exercise the padded send buffers of PooledGather."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    errors = []
+    try:
+        for _ in range(2):
+            rank, status, payload = ret.get(timeout=240)
+            if status != "ok":
+                errors.append("rank %d:\n%s" % (rank, payload))
+                break
+    finally:
+        for p in procs:
+            p.join(timeout=10 if errors else 120)
+            if p.is_alive():
+                p.kill()
+                p.join()
+    assert not errors, "\n".join(errors)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
