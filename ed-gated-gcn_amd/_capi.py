@@ -27,6 +27,7 @@ PROTOTYPES = {
     "ggcn_block_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                  c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "ggcn_overlap_reduce": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "ggcn_absmax": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "ggcn_subword_pool": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                                   c_i32, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_weight_pack_bytes": (c_sz, [c_i32, c_i32, c_i32]),

@@ -182,6 +182,11 @@ int ggcn_subword_pool(const float *A, int64_t sa_b, int64_t sa_r, int64_t sa_c, 
     return subword_pool(A, sa_b, sa_r, sa_c, X, x_batch, ldx, Y, y_batch, ldy, B, R, C, D, as_stream(stream));
 }
 
+int ggcn_absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float *out, ggcn_stream_t stream)
+{
+    return absmax(X, is_half, ld, M, K, out, as_stream(stream));
+}
+
 size_t ggcn_overlap_workspace_bytes(int B) { return overlap_workspace_bytes(B); }
 
 int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,

@@ -84,6 +84,8 @@ int weight_pack_rows(const float *W, int64_t ldw, int64_t K_valid, int F, int k_
 int dweight(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F, float *dW,
             int64_t lddw, void *workspace, hipStream_t st);
 
+int absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float *out, hipStream_t st);
+
 size_t overlap_workspace_bytes(int B);
 int gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,
                  hipStream_t st);

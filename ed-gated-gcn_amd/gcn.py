@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _capi
-from .csr import BatchedCSR
+from .csr import BatchedCSR, cached_from_dense
 
 
 def _require_gpu_f32(name, t, allow_half=False):
@@ -53,9 +53,6 @@ class _GatedLayerFunction(torch.autograd.Function):
         ctx.layer, ctx.csr = layer, csr
         ctx.save_for_backward(text, weight, out, store_gate, gate_a, gate_b)
         ctx.has_bias = bias is not None
-        for t in (pa, pb):
-            if t is None:
-                continue
         return out, pa, pb
 
     @staticmethod
@@ -140,8 +137,11 @@ class GraphConvolution(nn.Module):
         else:
             self.register_parameter("bias", None)
         # arithmetic of the dense linear: "bf16x3" (3 bf16 MFMAs per product, ~1e-5 abs), "f16mx8" (fp16 MFMA
-        # + one block-scaled fp8 correction MFMA, needs |x|,|w| < 65504) or "fp32" (exact fp32 MFMA)
-        self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "f16mx8")
+        # + one block-scaled fp8 correction MFMA, needs |x|,|w| < 65504) or "fp32" (exact fp32 MFMA).
+        # Default "bf16x3": it keeps the whole fp32 exponent range, so the one-line import switch never narrows
+        # what the reference's fp32 matmul accepts.  "f16mx8" (26 % faster) is opt-in: opt.ggcn_precision /
+        # GGCN_PRECISION, for activations of ordinary magnitude (validate_range() checks a batch).
+        self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "bf16x3")
         # one-launch layer (fused_layer.hip) when the batch allows it: T <= 32, binary adjacency, bf16x3
         self.fused = bool(getattr(opt, "ggcn_fused", True)) and os.environ.get("GGCN_FUSED", "1") != "0"
         # dense adjacency handed to forward(): None = let the device detect edge weights (one 4-byte
@@ -190,7 +190,7 @@ class GraphConvolution(nn.Module):
             raise RuntimeError("adj %s does not match text %s" % (tuple(adj.shape), tuple(text.shape)))
         if adj.device != text.device:
             raise RuntimeError("adj and text are on different devices")
-        return BatchedCSR.from_dense(adj, binary=self.binary_adj)  # gcn.py:33 accepts any real dtype
+        return cached_from_dense(adj, binary=self.binary_adj)  # gcn.py:33 accepts any real dtype
 
     def _check(self, text):
         # float16 features (BASELINE configs[3]) are an extension: the reference itself raises a
@@ -205,6 +205,31 @@ class GraphConvolution(nn.Module):
             raise RuntimeError("weight is on %s but text is on %s" % (self.weight.device, text.device))
         if self.precision not in _capi.PREC:
             raise RuntimeError("unknown precision %r (use 'bf16x3', 'f16mx8' or 'fp32')" % (self.precision,))
+
+    def validate_range(self, text=None):
+        """On-demand range check for ``precision='f16mx8'`` (one pass over the data, one read-back: NOT part of
+        ``forward``).  Returns ``{"text_absmax", "weight_absmax"}``; raises ``RuntimeError`` when the fp16 range
+        (|v| < 65504, finite) is exceeded -- where f16mx8 would saturate silently (f16mx8_core.h)."""
+        lib = _capi.load_library()
+        rep = {}
+        for name, t in (("weight", self.weight.detach()), ("text", text)):
+            if t is None:
+                continue
+            _require_gpu_f32(name, t, allow_half=True)
+            t2 = t.reshape(-1, t.shape[-1])
+            if t2.stride(1) != 1:
+                t2 = t2.contiguous()
+            out = torch.empty(2, dtype=torch.float32, device=t.device)
+            with torch.cuda.device(t.device):
+                _capi.check(lib.ggcn_absmax(_capi.ptr(t2), 1 if t2.dtype == torch.float16 else 0, t2.stride(0),
+                                            t2.shape[0], t2.shape[1], _capi.ptr(out), _capi.stream_of(t.device)),
+                            "ggcn_absmax")
+            amax, bad = out.tolist()
+            rep[name + "_absmax"] = amax
+            if bad or amax >= 65504.0:
+                raise RuntimeError("%s is outside the range of precision='f16mx8' (max |v| = %g%s; needs finite "
+                                   "|v| < 65504): use precision='bf16x3'" % (name, amax, ", non-finite entries" if bad else ""))
+        return rep
 
     def linear(self, x2d):
         """``hidden = text @ W`` (``gcn.py:34``) on [N,in] -> [N,out]."""

@@ -242,6 +242,12 @@ size_t ggcn_overlap_workspace_bytes(int B);
 int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy,
                       void *workspace, ggcn_stream_t stream);
 
+/* ---- range check for GGCN_PREC_F16MX8 (on demand, not on the forward path) ----------------
+ * out[0] = max |x| over the finite entries of X [M,K] (fp32, or IEEE half when is_half != 0; ld in
+ * elements), out[1] = 1.0f when some entry is NaN or infinite.  f16mx8 needs |x|, |w| < 65504 and keeps
+ * its full accuracy for |x| <= 448; the caller reads the two floats back when it wants the verdict. */
+int ggcn_absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float *out, ggcn_stream_t stream);
+
 /* ---- sub-word -> word pooling (the step before the path) ---------------
  * Replaces models/bert_amir5.py:600 `x = torch.bmm(transform, x)`:
  *   Y[b,r,:] = sum_c A[b,r,c] * X[b,c,:]

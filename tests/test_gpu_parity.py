@@ -905,3 +905,64 @@ def test_two_rank_sharded_block_same_device(pkg, dev):
                 p.join()
     assert not errors, "\n".join(errors)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+# ---------------------------------------------------------------- the drop-in forward(text, adj): syncs, cache, defaults
+def test_dropin_forward_is_sync_free_and_shares_the_conversion(pkg, dev):
+    """models/gcn.py:30-45 has no device synchronisation; neither has forward(text, dense adj) here when the
+    0/1 adjacency is promised (opt.ggcn_binary_adj) -- and without the promise the ONE read-back of the
+    weighted flag is paid once per adjacency tensor: gc1 and gc2 of a forward share the conversion."""
+    import types
+    from ed_gated_gcn_amd import csr as csr_mod, synth
+    B, T, H = 16, 31, 64
+    big = torch.zeros(B, 40, 40, device=dev)
+    big[:, :T, :T] = torch.from_numpy(synth.dependency_batch(B, T, 3.0, seed=2)).to(dev).float()
+    adj = big[:, :T, :T]                                  # the reference's non-contiguous slice (bert_amir5.py:589)
+    x = torch.randn(B, T, H, device=dev)
+    w, b = synth.layer_params(H, H, seed=1)
+    assert pkg.GraphConvolution(H, H, None).precision == "bf16x3"        # the drop-in default keeps the fp32 range
+    promised = types.SimpleNamespace(ggcn_binary_adj=True)
+    gc1, gc2 = pkg.GraphConvolution(H, H, promised).to(dev), pkg.GraphConvolution(H, H, promised).to(dev)
+    plain1, plain2 = pkg.GraphConvolution(H, H, None).to(dev), pkg.GraphConvolution(H, H, None).to(dev)
+    with torch.no_grad():
+        for m in (gc1, gc2, plain1, plain2):
+            m.weight.copy_(torch.from_numpy(w)); m.bias.copy_(torch.from_numpy(b))
+        ref = gc2(gc1(x, adj), adj)                       # warm-up: packs the weights
+        want = plain2(plain1(x, adj), adj)                # un-promised: converts (and reads the flag back) once
+        torch.cuda.synchronize()
+        n_cached = len(csr_mod._RECENT)
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            got = gc2(gc1(x, adj), adj)                   # promised 0/1 adjacency: zero host syncs
+            again = plain2(plain1(x, adj), adj)           # same adjacency tensor again: cache hit, zero host syncs
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    assert len(csr_mod._RECENT) == n_cached
+    assert torch.equal(got, ref) and torch.equal(again, want) and torch.equal(got, want)
+    # an in-place edit of the adjacency is a new adjacency: the cache must not serve the old conversion
+    with torch.no_grad():
+        big[:, 0, 1] = 1.0
+        big[:, 1, 0] = 1.0
+        edited = plain1(x, adj)
+        fresh = plain1(x, adj.clone())
+    assert torch.equal(edited, fresh)
+
+
+def test_f16mx8_range_validation_is_loud(pkg, dev):
+    """f16mx8 is opt-in and saturates beyond the fp16 range; validate_range() is the explicit check."""
+    import types
+    H = 64
+    m = pkg.GraphConvolution(H, H, types.SimpleNamespace(ggcn_precision="f16mx8")).to(dev)
+    assert m.precision == "f16mx8"
+    with torch.no_grad():
+        m.weight.normal_(0, 0.05); m.bias.zero_()
+    x = torch.randn(3, 7, H, device=dev)
+    rep = m.validate_range(x)
+    assert abs(rep["text_absmax"] - float(x.abs().max())) < 1e-6 and rep["weight_absmax"] < 1.0
+    x[1, 2, 3] = 7.0e4
+    with pytest.raises(RuntimeError, match="outside the range"):
+        m.validate_range(x)
+    x[1, 2, 3] = float("nan")
+    with pytest.raises(RuntimeError, match="non-finite"):
+        m.validate_range(x)
+    assert m.validate_range(x.half().nan_to_num(0.0))["text_absmax"] > 0      # fp16 features too
