@@ -21,6 +21,7 @@ PROTOTYPES = {
     "ggcn_csr_from_dense": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp,
                                     c_i64, c_vp, c_vp, c_vp, c_vp]),
     "ggcn_rowmask_from_dense": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "ggcn_csr_transpose": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ggcn_csr_rowmask": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_layer_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                  c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
@@ -36,7 +37,9 @@ PROTOTYPES = {
     "ggcn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                c_vp, c_i64, c_vp, c_vp, c_vp]),
     "ggcn_gate_pool_backward": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32,
-                                        c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+                                        c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ggcn_colsum_workspace_bytes": (c_sz, [c_i32]),
+    "ggcn_colsum": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "ggcn_dweight_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32, c_i32]),
     "ggcn_dweight": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "ggcn_inv_denominators": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),

@@ -44,7 +44,7 @@ class BatchedCSR:
     kernel: all the fused layer needs); the CSR arrays are materialised on first access."""
 
     __slots__ = ("_rowptr", "_colidx", "_vals", "rowmask", "B", "T", "nnz", "is_binary",
-                 "_dense", "_dense_version", "_host", "_t", "_inv", "__weakref__")
+                 "_dense", "_dense_version", "_t", "_inv", "__weakref__")
 
     def __init__(self, rowptr, colidx, vals, B, T, nnz=None, rowmask=None):
         self._rowptr, self._colidx, self._vals, self.rowmask = rowptr, colidx, vals, rowmask
@@ -52,7 +52,6 @@ class BatchedCSR:
         self.is_binary = vals is None
         self._dense = None   # the dense tensor this CSR was built from (lazy arrays, transposed())
         self._dense_version = None
-        self._host = None    # (rowptr, colidx, vals) numpy arrays when built on the host
         self._t = None       # cached CSR of the transposed adjacency (backward pass)
         self._inv = None     # cached 1/(rowsum+1) per node
 
@@ -181,25 +180,28 @@ class BatchedCSR:
             mask = torch.from_numpy(m.view(np.int32)).to(device)
         out = cls(torch.from_numpy(rowptr).to(device), torch.from_numpy(colidx).to(device), v, B, T,
                   nnz=int(colidx.shape[0]), rowmask=mask)
-        out._host = (rowptr, colidx, None if v is None else np.ascontiguousarray(vals, dtype=np.float32))
         return out
 
     def transposed(self):
         """CSR of the transposed adjacency (rows = source nodes), cached: the backward pass applies
-        A^T.  Built from the dense tensor by swapping its strides, or on the host from the arrays."""
+        A^T.  Built from the dense tensor by swapping its strides, or from the CSR arrays by ``ggcn_csr_transpose``."""
         if self._t is None:
             if self._dense is not None:
                 self._t = BatchedCSR.from_dense(self._source().transpose(1, 2), binary=self.is_binary)
-            elif self._host is not None:
-                import numpy as np
-                import scipy.sparse as sp
-                rowptr, colidx, vals = self._host
-                n = self.B * self.T
-                data = np.ones(len(colidx), dtype=np.float32) if vals is None else vals
-                mt = sp.csr_matrix((data, colidx, rowptr), shape=(n, n)).T.tocsr()
-                mt.sort_indices()
-                self._t = BatchedCSR.from_arrays(mt.indptr, mt.indices, self.B, self.T, self.device,
-                                                 vals=None if vals is None else mt.data)
+            elif self._rowptr is not None and self.nnz is not None:
+                # built from arrays (GraphBatcher.collate, from_arrays): transposed on the device, graph by graph
+                lib = _capi.load_library()
+                dev = self.device
+                n = self.n_nodes
+                rp = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                ci = torch.empty(max(1, self.nnz), dtype=torch.int32, device=dev)
+                va = None if self._vals is None else torch.empty(max(1, self.nnz), dtype=torch.float32, device=dev)
+                ws = torch.empty(n, dtype=torch.int32, device=dev)
+                with torch.cuda.device(dev):
+                    _capi.check(lib.ggcn_csr_transpose(_capi.ptr(self._rowptr), _capi.ptr(self._colidx), _capi.ptr(self._vals),
+                                                       self.B, self.T, _capi.ptr(rp), _capi.ptr(ci), _capi.ptr(va),
+                                                       _capi.ptr(ws), _capi.stream_of(dev)), "ggcn_csr_transpose")
+                self._t = BatchedCSR(rp, ci, va, self.B, self.T, nnz=self.nnz)
             else:
                 raise RuntimeError("this BatchedCSR was assembled by hand: no source to transpose from")
             self._t._t = self

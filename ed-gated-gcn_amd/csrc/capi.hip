@@ -43,6 +43,12 @@ int ggcn_csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t st
                           capacity, rowmask, flags, workspace, as_stream(stream));
 }
 
+int ggcn_csr_transpose(const int32_t *rowptr, const int32_t *colidx, const float *vals, int B, int T,
+                       int32_t *rowptr_t, int32_t *colidx_t, float *vals_t, void *workspace, ggcn_stream_t stream)
+{
+    return csr_transpose(rowptr, colidx, vals, B, T, rowptr_t, colidx_t, vals_t, workspace, as_stream(stream));
+}
+
 int ggcn_rowmask_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t stride_b, int64_t stride_r,
                             int64_t stride_c, uint32_t *rowmask, int32_t *flags, ggcn_stream_t stream)
 {
@@ -154,10 +160,17 @@ int ggcn_aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const i
 int ggcn_gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                             const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                             const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
-                            float *d_ga, float *d_gb, ggcn_stream_t stream)
+                            float *d_ga, float *d_gb, float *d_bsum, ggcn_stream_t stream)
 {
     return gate_pool_backward(out, ldo, store_gate, gate_a, gate_b, d_out, ldd, d_pa, d_pb, B, T, F, dY, ldy, d_sg,
-                              d_ga, d_gb, as_stream(stream));
+                              d_ga, d_gb, d_bsum, as_stream(stream));
+}
+
+size_t ggcn_colsum_workspace_bytes(int F) { return colsum_workspace_bytes(F); }
+
+int ggcn_colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *workspace, ggcn_stream_t stream)
+{
+    return colsum(X, ld, M, F, out, workspace, as_stream(stream));
 }
 
 size_t ggcn_dweight_workspace_bytes(int64_t n_rows, int K, int F, int precision)

@@ -31,6 +31,8 @@ int csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int
                    int32_t *rowptr, int32_t *colidx, float *vals, int64_t capacity, uint32_t *rowmask,
                    int32_t *flags, void *workspace, hipStream_t st);
 size_t csr_workspace_bytes(int64_t n_rows);
+int csr_transpose(const int32_t *rowptr, const int32_t *colidx, const float *vals, int B, int T, int32_t *rowptr_t,
+                  int32_t *colidx_t, float *vals_t, void *workspace, hipStream_t st);
 int rowmask_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int64_t sr, int64_t sc,
                        uint32_t *rowmask, int32_t *flags, hipStream_t st);
 
@@ -74,7 +76,9 @@ int overlap_reduce(const float *partials, int B, int F, float *xy, hipStream_t s
 int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                        const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                        const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
-                       float *d_ga, float *d_gb, hipStream_t st);
+                       float *d_ga, float *d_gb, float *d_bsum, hipStream_t st);
+size_t colsum_workspace_bytes(int F);
+int colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *workspace, hipStream_t st);
 
 size_t dweight_workspace_bytes(int64_t N, int K, int F);
 size_t dweight_bx3_workspace_bytes(int64_t N, int K, int F);

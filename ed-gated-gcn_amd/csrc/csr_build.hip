@@ -197,7 +197,63 @@ int run(const void *adj, int B, int T, int64_t sb, int64_t sr, int64_t sc, int32
     return check_launch("ggcn_csr_from_dense");
 }
 
+// Transposed batched CSR (the backward pass applies A^T, train.py:120).  The adjacency is block-diagonal with
+// blocks of T rows, so graph g's entries occupy the SAME range [rowptr[gT], rowptr[(g+1)T]) in both CSRs: one
+// workgroup per graph, no global scan.  Thread j (a column of A = a row of A^T) counts its entries, a serial
+// scan over the T counts gives the row pointers, then it walks the rows i in ascending order and copies its
+// entries: the transposed rows come out sorted by column, deterministically.  O(T * nnz_g) per graph.
+__global__ __launch_bounds__(256) void csr_transpose_kernel(const int32_t *__restrict__ rowptr,
+                                                            const int32_t *__restrict__ colidx,
+                                                            const float *__restrict__ vals, int T,
+                                                            int32_t *__restrict__ rowptr_t, int32_t *__restrict__ colidx_t,
+                                                            float *__restrict__ vals_t, int32_t *__restrict__ scratch)
+{
+    const int g = blockIdx.x;
+    const int64_t base = (int64_t)g * T;
+    const int e0 = rowptr[base], e1 = rowptr[base + T];
+    int32_t *cnt = scratch + base;          // T counters of this graph (global scratch: T is not bounded by LDS)
+    for (int j = threadIdx.x; j < T; j += 256) {
+        int c = 0;
+        for (int e = e0; e < e1; ++e) c += (colidx[e] - base == j);
+        cnt[j] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = e0;
+        for (int j = 0; j < T; ++j) {
+            const int c = cnt[j];
+            rowptr_t[base + j] = run;
+            cnt[j] = run;
+            run += c;
+        }
+        if (g == (int)gridDim.x - 1) rowptr_t[base + T] = e1;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < T; j += 256) {
+        int pos = cnt[j];
+        for (int i = 0; i < T; ++i)
+            for (int e = rowptr[base + i]; e < rowptr[base + i + 1]; ++e)
+                if (colidx[e] - base == j) {
+                    colidx_t[pos] = (int32_t)(base + i);
+                    if (vals_t) vals_t[pos] = vals ? vals[e] : 1.0f;
+                    ++pos;
+                }
+    }
+}
+
 }  // namespace
+
+int csr_transpose(const int32_t *rowptr, const int32_t *colidx, const float *vals, int B, int T, int32_t *rowptr_t,
+                  int32_t *colidx_t, float *vals_t, void *workspace, hipStream_t st)
+{
+    if (!rowptr || !colidx || !rowptr_t || !colidx_t || !workspace) return fail(GGCN_EINVAL, "ggcn_csr_transpose: null pointer");
+    if (B <= 0 || T <= 0) return fail(GGCN_EINVAL, "ggcn_csr_transpose: B=%d T=%d must be positive", B, T);
+    if ((vals != nullptr) != (vals_t != nullptr))
+        return fail(GGCN_EINVAL, "ggcn_csr_transpose: vals and vals_t go together (both NULL for a 0/1 adjacency)");
+    hipLaunchKernelGGL(csr_transpose_kernel, dim3((unsigned)B), dim3(256), 0, st, rowptr, colidx, vals, T, rowptr_t,
+                       colidx_t, vals_t, static_cast<int32_t *>(workspace));
+    return check_launch("ggcn_csr_transpose");
+}
 
 size_t csr_workspace_bytes(int64_t n_rows)
 {

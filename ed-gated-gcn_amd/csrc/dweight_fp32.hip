@@ -17,6 +17,8 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int TM = 128, TN = 128, TR = 16;   // output rows (k), output cols (f), reduction rows (n)
 constexpr int LDS_LD = 128 + 4;
 
+// VEC: rows of X and dH are 16-byte aligned (ld % 4 == 0, aligned base): 16-byte loads; otherwise element loads
+template <bool VEC>
 __global__ __launch_bounds__(256) void dweight_partial_kernel(
     const float *__restrict__ X, int64_t ldx, const float *__restrict__ G, int64_t ldg,
     int64_t N, int K, int F, int64_t rows_per_slice, float *__restrict__ slabs)
@@ -40,10 +42,12 @@ __global__ __launch_bounds__(256) void dweight_partial_kernel(
             if (n < n_end) {
                 const float *px = X + n * ldx + k0 + s_c;
                 const float *pg = G + n * ldg + f0 + s_c;
-                if (k0 + s_c + 3 < K) a = *reinterpret_cast<const float4 *>(px);
-                else { if (k0 + s_c < K) a.x = px[0]; if (k0 + s_c + 1 < K) a.y = px[1]; if (k0 + s_c + 2 < K) a.z = px[2]; }
-                if (f0 + s_c + 3 < F) b = *reinterpret_cast<const float4 *>(pg);
-                else { if (f0 + s_c < F) b.x = pg[0]; if (f0 + s_c + 1 < F) b.y = pg[1]; if (f0 + s_c + 2 < F) b.z = pg[2]; }
+                if (VEC && k0 + s_c + 3 < K) a = *reinterpret_cast<const float4 *>(px);
+                else { if (k0 + s_c < K) a.x = px[0]; if (k0 + s_c + 1 < K) a.y = px[1]; if (k0 + s_c + 2 < K) a.z = px[2];
+                       if (!VEC && k0 + s_c + 3 < K) a.w = px[3]; }
+                if (VEC && f0 + s_c + 3 < F) b = *reinterpret_cast<const float4 *>(pg);
+                else { if (f0 + s_c < F) b.x = pg[0]; if (f0 + s_c + 1 < F) b.y = pg[1]; if (f0 + s_c + 2 < F) b.z = pg[2];
+                       if (!VEC && f0 + s_c + 3 < F) b.w = pg[3]; }
             }
             ra[h] = a; rb[h] = b;
         }
@@ -131,13 +135,13 @@ int dweight(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N,
     if (!X || !G || !dW || !workspace) return fail(GGCN_EINVAL, "ggcn_dweight: null pointer");
     if (N <= 0 || K <= 0 || F <= 0) return fail(GGCN_EINVAL, "ggcn_dweight: N=%lld K=%d F=%d must be positive", (long long)N, K, F);
     if (ldx < K || ldg < F || lddw < F) return fail(GGCN_EINVAL, "ggcn_dweight: leading dimension too small");
-    if ((ldx % 4) || (ldg % 4) || !aligned16(X) || !aligned16(G))
-        return fail(GGCN_EUNSUPPORTED, "ggcn_dweight: X and dH rows must be 16-byte aligned (ld %% 4 == 0)");
+    const bool vec = !((ldx % 4) || (ldg % 4) || !aligned16(X) || !aligned16(G));
     const int S = n_slices_for(N, K, F);
     const int64_t rows = ((N + S - 1) / S + TR - 1) / TR * TR;
     float *slabs = static_cast<float *>(workspace);
     dim3 grid((unsigned)((F + TN - 1) / TN), (unsigned)((K + TM - 1) / TM), (unsigned)S);
-    hipLaunchKernelGGL(dweight_partial_kernel, grid, dim3(256), 0, st, X, ldx, G, ldg, N, K, F, rows, slabs);
+    if (vec) hipLaunchKernelGGL(dweight_partial_kernel<true>, grid, dim3(256), 0, st, X, ldx, G, ldg, N, K, F, rows, slabs);
+    else hipLaunchKernelGGL(dweight_partial_kernel<false>, grid, dim3(256), 0, st, X, ldx, G, ldg, N, K, F, rows, slabs);
     const int64_t kf = (int64_t)K * F;
     hipLaunchKernelGGL(dweight_reduce_kernel, dim3((unsigned)((kf + 255) / 256)), dim3(256), 0, st, slabs, S, kf, K, F,
                        dW, lddw);

@@ -6,6 +6,7 @@
 // Given d_out [N,F] (optional), d_pa, d_pb [B,F] (optional):
 //     dY[t]   = d_out[t]*sg + [t = argmax_a] d_pa*ga + [t = argmax_b] d_pb*gb
 //     d_sg    = sum_t d_out[t]*y[t]      d_ga = d_pa * y[argmax_a]      d_gb = d_pb * y[argmax_b]
+//     d_bsum  = sum_t dY[t]              (per graph; ggcn_colsum over the graphs then gives db = sum_rows dY)
 // y is recovered as out/sg when a store gate was applied (sigmoid gates are > 0; sg == 0 -> y := 0),
 // argmax = the FIRST row attaining the maximum of y*g (torch.max's choice, bert_amir5.py:635).
 // Mapping: workgroup = (graph, 256-column slab), thread = one column, loop over the T rows twice
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void gate_pool_backward_kernel(
     const float *__restrict__ gate_a, const float *__restrict__ gate_b,
     const float *__restrict__ d_out, int64_t ldd, const float *__restrict__ d_pa,
     const float *__restrict__ d_pb, int T, int F, int n_slabs, float *__restrict__ dY, int64_t ldy,
-    float *__restrict__ d_sg, float *__restrict__ d_ga, float *__restrict__ d_gb)
+    float *__restrict__ d_sg, float *__restrict__ d_ga, float *__restrict__ d_gb, float *__restrict__ d_bsum)
 {
     const int b = blockIdx.x / n_slabs;
     const int f = (blockIdx.x - b * n_slabs) * 256 + threadIdx.x;
@@ -44,23 +45,67 @@ __global__ __launch_bounds__(256) void gate_pool_backward_kernel(
         if (vb > best_b) { best_b = vb; ib = t; yb = y; }
         if (d_out) acc_sg = fmaf(d_out[((int64_t)b * T + t) * ldd + f], y, acc_sg);
     }
+    float bsum = 0.0f;
     for (int t = 0; t < T; ++t) {
         float g = d_out ? d_out[((int64_t)b * T + t) * ldd + f] * sg : 0.0f;
         if (d_pa && t == ia) g = fmaf(dpa, ga, g);
         if (d_pb && t == ib) g = fmaf(dpb, gb, g);
         dY[((int64_t)b * T + t) * ldy + f] = g;
+        bsum += g;
     }
+    if (d_bsum) d_bsum[gf] = bsum;
     if (d_sg) d_sg[gf] = acc_sg;
     if (d_ga) d_ga[gf] = dpa * ya;
     if (d_gb) d_gb[gf] = dpb * yb;
 }
 
+// out[f] = sum_r X[r, f], deterministic: S row slabs each leave a partial row (fixed order inside a slab: the 4
+// wavefronts take rows r = w, w+4, ... and are added (w0+w1)+(w2+w3)), then the slabs are added in order.
+constexpr int kColsumSlabs = 64;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ X, int64_t ld, int64_t M, int F,
+                                                             int64_t rows_per_slab, float *__restrict__ part)
+{
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+    const int64_t r1 = r0 + rows_per_slab < M ? r0 + rows_per_slab : M;
+    float s = 0.0f;
+    if (f < F)
+        for (int64_t r = r0 + w; r < r1; r += 4) s += X[r * ld + f];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && f < F) part[(int64_t)blockIdx.y * F + f] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, int S, int F, float *__restrict__ out)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    float s = 0.0f;
+    for (int z = 0; z < S; ++z) s += part[(int64_t)z * F + f];
+    out[f] = s;
+}
+
 }  // namespace
+
+size_t colsum_workspace_bytes(int F) { return F > 0 ? (size_t)kColsumSlabs * F * sizeof(float) : 0; }
+
+int colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *workspace, hipStream_t st)
+{
+    if (!X || !out || !workspace) return fail(GGCN_EINVAL, "ggcn_colsum: null pointer");
+    if (M <= 0 || F <= 0 || ld < F) return fail(GGCN_EINVAL, "ggcn_colsum: M=%lld F=%d ld=%lld", (long long)M, F, (long long)ld);
+    const int S = (int)(M < kColsumSlabs ? M : kColsumSlabs);
+    const int64_t rows = (M + S - 1) / S;
+    float *part = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((F + 63) / 64), (unsigned)S), dim3(256), 0, st, X, ld, M, F, rows, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, part, S, F, out);
+    return check_launch("ggcn_colsum");
+}
 
 int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                        const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                        const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
-                       float *d_ga, float *d_gb, hipStream_t st)
+                       float *d_ga, float *d_gb, float *d_bsum, hipStream_t st)
 {
     if (!out || !dY) return fail(GGCN_EINVAL, "ggcn_gate_pool_backward: null pointer");
     if (B <= 0 || T <= 0 || F <= 0)
@@ -71,7 +116,7 @@ int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, c
     const int64_t blocks = (int64_t)B * n_slabs;
     if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_gate_pool_backward: grid too large");
     hipLaunchKernelGGL(gate_pool_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, ldo, store_gate,
-                       gate_a, gate_b, d_out, ldd, d_pa, d_pb, T, F, n_slabs, dY, ldy, d_sg, d_ga, d_gb);
+                       gate_a, gate_b, d_out, ldd, d_pa, d_pb, T, F, n_slabs, dY, ldy, d_sg, d_ga, d_gb, d_bsum);
     return check_launch("ggcn_gate_pool_backward");
 }
 

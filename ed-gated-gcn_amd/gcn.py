@@ -41,7 +41,7 @@ class _GatedLayerFunction(torch.autograd.Function):
         dX = dH.W^T            HIP bf16x3 MFMA linear on the packed W^T
         dW = X^T.dH            HIP split-K: bf16x3 main loop on X^T and packed dH (dweight_bx3.hip), or the
                                exact-fp32 MFMA form for precision 'fp32' (dweight_fp32.hip)
-        db = sum_rows dY
+        db = sum_rows dY       HIP: per-graph sums from the gate/pool pass + ggcn_colsum
     """
 
     @staticmethod
@@ -81,10 +81,11 @@ class _GatedLayerFunction(torch.autograd.Function):
             d_sg = torch.empty(B, F, dtype=torch.float32, device=dev) if (store_gate is not None and need[3]) else None
             d_ga = torch.empty(B, F, dtype=torch.float32, device=dev) if (gate_a is not None and need[4] and d_pa is not None) else None
             d_gb = torch.empty(B, F, dtype=torch.float32, device=dev) if (gate_b is not None and need[5] and d_pb is not None) else None
+            d_bsum = torch.empty(B, F, dtype=torch.float32, device=dev) if (ctx.has_bias and need[2]) else None
             _capi.check(lib.ggcn_gate_pool_backward(
                 _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),
                 _capi.ptr(d_out2), F, _capi.ptr(d_pa), _capi.ptr(d_pb), B, T, F, _capi.ptr(dy), F,
-                _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), st), "ggcn_gate_pool_backward")
+                _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), _capi.ptr(d_bsum), st), "ggcn_gate_pool_backward")
             dh = torch.empty(B * T, F, dtype=torch.float32, device=dev)
             _capi.check(lib.ggcn_aggregate_t(_capi.ptr(dy), F, _capi.ptr(csr_t.rowptr), _capi.ptr(csr_t.colidx),
                                              _capi.ptr(csr_t.vals), _capi.ptr(inv), B, T, F, _capi.ptr(dh), F, st),
@@ -110,17 +111,15 @@ class _GatedLayerFunction(torch.autograd.Function):
                 # split-precision layers: bf16x3 on the forward's main loop (fp32 exponent range, ~1e-5);
                 # precision "fp32": the exact fp32 MFMA form, which wants 16-byte aligned rows
                 prec = "bf16x3" if layer.precision in _capi.PACKED else "fp32"
-                aligned = x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0 and F % 4 == 0
-                if prec == "fp32" and not aligned:
-                    dw = x2d.t().matmul(dh)   # rows that cannot be 16-byte aligned: plain library GEMM
-                else:
-                    dw = torch.empty(K, F, dtype=torch.float32, device=dev)
-                    ws = torch.empty(lib.ggcn_dweight_workspace_bytes(B * T, K, F, _capi.PREC[prec]),
-                                     dtype=torch.uint8, device=dev)
-                    _capi.check(lib.ggcn_dweight(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(dh), F, B * T, K, F,
-                                                 _capi.ptr(dw), F, _capi.PREC[prec], _capi.ptr(ws), st), "ggcn_dweight")
-            if ctx.has_bias and need[2]:
-                db = dy.sum(dim=0)
+                dw = torch.empty(K, F, dtype=torch.float32, device=dev)
+                ws = torch.empty(lib.ggcn_dweight_workspace_bytes(B * T, K, F, _capi.PREC[prec]),
+                                 dtype=torch.uint8, device=dev)
+                _capi.check(lib.ggcn_dweight(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(dh), F, B * T, K, F,
+                                             _capi.ptr(dw), F, _capi.PREC[prec], _capi.ptr(ws), st), "ggcn_dweight")
+            if d_bsum is not None:   # db = sum_rows dY: per-graph sums from the pass above, added over the graphs
+                db = torch.empty(F, dtype=torch.float32, device=dev)
+                ws = torch.empty(lib.ggcn_colsum_workspace_bytes(F), dtype=torch.uint8, device=dev)
+                _capi.check(lib.ggcn_colsum(_capi.ptr(d_bsum), F, B, F, _capi.ptr(db), _capi.ptr(ws), st), "ggcn_colsum")
         return dx, dw, db, d_sg, d_ga, d_gb, None, None, None, None
 
 

@@ -100,6 +100,13 @@ int ggcn_rowmask_from_dense(const void *adj, int adj_dtype, int B, int T,
                             int64_t stride_b, int64_t stride_r, int64_t stride_c,
                             uint32_t *rowmask, int32_t *flags, ggcn_stream_t stream);
 
+/* Transposed batched CSR (rows = source nodes): the backward pass applies A^T (train.py:120).  rowptr_t
+ * int32[N+1], colidx_t int32[nnz], vals_t fp32[nnz] or NULL together with vals; rows of the result are sorted
+ * by column; workspace: 4*B*T bytes.  One workgroup per graph (the adjacency is block-diagonal). */
+int ggcn_csr_transpose(const int32_t *rowptr, const int32_t *colidx, const float *vals, int B, int T,
+                       int32_t *rowptr_t, int32_t *colidx_t, float *vals_t, void *workspace,
+                       ggcn_stream_t stream);
+
 /* Row masks from an existing batched CSR (T <= 32). */
 int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
                      uint32_t *rowmask, ggcn_stream_t stream);
@@ -147,13 +154,14 @@ int ggcn_aggregate(const float *Hd, int64_t ldh,
  *                     (packs the transpose of the stored matrix: the packed operand has
  *                     K = F_layer rows and F = K_layer columns)
  *   dW = X^T.dH       ggcn_dweight, split over the node rows, deterministic (fixed-order slab sum):
- *                     GGCN_PREC_FP32  exact fp32 MFMA on the rows as they lie;
+ *                     GGCN_PREC_FP32  exact fp32 MFMA on the rows as they lie (16-byte row loads when
+ *                     aligned, element loads otherwise);
  *                     GGCN_PREC_BF16X3  X is transposed and dH packed once, then the forward's
  *                     bf16x3 main loop runs split-K (about 3x faster at config 2; needs
  *                     ~2 x 4*N*max(K,F) bytes of workspace).  f16mx8 is refused: gradients need
  *                     the fp32 exponent range.  (workspace: ggcn_dweight_workspace_bytes(N, K, F,
  *                     precision) bytes, 16-byte aligned)
- *   db = sum_rows dY  a plain column sum on the caller's side. */
+ *   db = sum_rows dY  ggcn_gate_pool_backward's d_bsum (per graph) + ggcn_colsum over the graphs. */
 /* Backward of the gate / max-pool epilogue (models/bert_amir5.py:627-640): from the stored
  * layer output `out` (= y*store_gate), the gates and the upstream gradients of out and of the
  * two pooled outputs, produce dY (gradient of the ungated layer output y) and the gate gradients:
@@ -164,7 +172,12 @@ int ggcn_gate_pool_backward(const float *out, int64_t ldo,
                             const float *store_gate, const float *gate_a, const float *gate_b,
                             const float *d_out, int64_t ldd, const float *d_pa, const float *d_pb,
                             int B, int T, int F, float *dY, int64_t ldy,
-                            float *d_sg, float *d_ga, float *d_gb, ggcn_stream_t stream);
+                            float *d_sg, float *d_ga, float *d_gb, float *d_bsum, ggcn_stream_t stream);
+/* d_bsum (NULL or [B,F]) receives sum_t dY per graph; db = sum_rows dY is then ggcn_colsum over its B rows.
+ * ggcn_colsum: out[f] = sum_r X[r,f] for X [M, ld], deterministic (fixed-order slab sums);
+ * workspace: ggcn_colsum_workspace_bytes(F) bytes. */
+size_t ggcn_colsum_workspace_bytes(int F);
+int ggcn_colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *workspace, ggcn_stream_t stream);
 size_t ggcn_dweight_workspace_bytes(int64_t n_rows, int K, int F, int precision);
 int ggcn_dweight(const float *X, int64_t ldx, const float *dH, int64_t ldg, int64_t n_rows, int K, int F,
                  float *dW, int64_t lddw, int precision, void *workspace, ggcn_stream_t stream);
