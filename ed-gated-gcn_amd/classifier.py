@@ -5,14 +5,17 @@ Sub-module names, shapes and construction order follow the reference, so a refer
 ``state_dict`` loads unchanged (``bert.*``, ``dense``, ``lstm``, ``gc1``, ``gc2``, ``gate1``,
 ``gate2``, ``fc``) and ``Instructor._reset_params`` (``train.py:75-84``) initialises it the same
 way.  ``forward(inputs) -> (logits, gate_reg, kl_reg, scores)`` like every live model of
-``train.py:109``.  The sub-word pooling (``:600``) and the block (``:621-640``) run on the HIP path;
-BERT, the BiLSTM and the small heads stay PyTorch-ROCm.
+``train.py:109``.  The sub-word pooling (``:600``), the gate MLPs (``:562-571``), the block (``:621-640``) and the
+``scores`` / ``kl`` head (``:645-648``) run on the HIP path in inference; under autograd the gate MLPs and the
+head keep the reference's PyTorch ops (they are trained), and with dropout active the gates are dropped per
+token like the reference's (``:621-625``).  BERT, the BiLSTM and ``dense`` stay PyTorch-ROCm.
 """
 import torch
 import torch.nn as nn
 
 from .gated_block import gated_gcn_block
 from .gcn import GraphConvolution
+from .heads import gate_mlps, scores_and_kl
 from .pooling import subword_pool
 
 
@@ -69,13 +72,37 @@ class GatedGCNEventDetector(nn.Module):
         anchor_rep = self.dropout(x[rows, anchor])                          # :604-608: the anchor token's row
         x, _ = self.lstm(x)                                                 # :610
         aspect = x[rows, anchor]                                            # :615-618
-        gate1 = self.dropout(self.gate1(aspect))                            # :621-625, kept [B,H] (no repeat)
-        gate2 = self.dropout(self.gate2(aspect))
-        r = gated_gcn_block(x.contiguous(), adj, gate1.contiguous(), gate2.contiguous(),
-                            self.gc1, self.gc2)                             # :626-640 on the HIP path
-        out = self.dropout(r["out"])                                        # :642
+        x = x.contiguous()
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not grad:
+            # ---- inference: everything from `aspect` to `scores` on the HIP path, gates kept [B,H] ----
+            gate1, gate2 = gate_mlps(aspect.contiguous(), self.gate1, self.gate2)     # :562-571,621-622, one launch
+            r = gated_gcn_block(x, adj, gate1, gate2, self.gc1, self.gc2)             # :626-640, one launch (T <= 32)
+            logits = self.dense(torch.cat([anchor_rep, aspect, r["out"]], dim=1))     # :642-643 (dropout = identity)
+            scores, kl = scores_and_kl(r["x"], aspect, logits, self.fc[0], dist)      # :645-648, one launch
+            return logits, r["xy"], kl, scores
+        if self.training and self.dropout.p > 0:
+            # ---- training with dropout: the reference drops entries of the REPEATED [B,T,H] gates (:621-625), one
+            # mask per token, so the gate multiply and the max cannot ride on a [B,H] gate.  The two layers run on
+            # the HIP path (forward and backward); gating, dropout and the pools are the reference's own ops. ----
+            gate1 = self.dropout(self.gate1(aspect)[:, None, :].expand(-1, T, -1))     # :621-624 (repeat, then dropout)
+            gate2 = self.dropout(self.gate2(aspect)[:, None, :].expand(-1, T, -1))
+            gcn1 = self.gc1(x, adj)                                                    # :626
+            x1 = torch.max(gcn1 * gate1, 1)[0]                                         # :627-635
+            y1 = torch.max(gcn1 * gate2, 1)[0]                                         # :631-636
+            xy = (x1 * y1).sum(1).mean()                                               # :638
+            xg = gate2 * self.gc2(gcn1, adj)                                           # :639
+            out = torch.max(xg, dim=1)[0]                                              # :640
+            if pooled is not None:
+                self.dropout(pooled)                                                   # :641 (unused; keeps the RNG stream)
+        else:
+            gate1 = self.gate1(aspect)                                                 # dropout is the identity here
+            gate2 = self.gate2(aspect)
+            r = gated_gcn_block(x, adj, gate1.contiguous(), gate2.contiguous(), self.gc1, self.gc2)   # :626-640
+            xy, xg, out = r["xy"], r["x"], r["out"]
+        out = self.dropout(out)                                             # :642
         logits = self.dense(torch.cat([anchor_rep, aspect, out], dim=1))    # :643
-        output_w = self.fc(torch.cat([r["x"], aspect[:, None, :].expand(-1, T, -1)], dim=2))   # :645
+        output_w = self.fc(torch.cat([xg, aspect[:, None, :].expand(-1, T, -1)], dim=2))   # :645
         scores = (logits[:, None, :] * output_w).sum(2)                     # :646
         kl = (torch.softmax(scores, 1) * torch.softmax(dist.float(), 1)).sum(1).mean()          # :648
-        return logits, r["xy"], kl, scores
+        return logits, xy, kl, scores

@@ -200,6 +200,26 @@ int ggcn_absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float 
     return absmax(X, is_half, ld, M, K, out, as_stream(stream));
 }
 
+int ggcn_transpose(const float *W, int rows, int cols, int64_t ldw, float *Wt, ggcn_stream_t stream)
+{
+    return transpose_f32(W, rows, cols, ldw, Wt, as_stream(stream));
+}
+
+int ggcn_gate_mlp(const float *aspect, int64_t lda, int B, int H, const float *w1t_a, const float *b1_a,
+                  const float *w2t_a, const float *b2_a, float *gate_a, const float *w1t_b, const float *b1_b,
+                  const float *w2t_b, const float *b2_b, float *gate_b, ggcn_stream_t stream)
+{
+    return gate_mlp(aspect, lda, B, H, w1t_a, b1_a, w2t_a, b2_a, gate_a, w1t_b, b1_b, w2t_b, b2_b, gate_b, as_stream(stream));
+}
+
+int ggcn_scores_head(const float *X, int64_t ldx, const float *aspect, int64_t lda, const float *logits, int64_t ldl,
+                     const float *fc_weight, int64_t ldw, const float *fc_bias, const float *dist, int64_t ldd, int B,
+                     int T, int H, int C, float *scores, int64_t ld_scores, float *kl_part, ggcn_stream_t stream)
+{
+    return scores_head(X, ldx, aspect, lda, logits, ldl, fc_weight, ldw, fc_bias, dist, ldd, B, T, H, C, scores, ld_scores,
+                       kl_part, as_stream(stream));
+}
+
 size_t ggcn_overlap_workspace_bytes(int B) { return overlap_workspace_bytes(B); }
 
 int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,

@@ -90,6 +90,14 @@ int dweight(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N,
 
 int absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float *out, hipStream_t st);
 
+int transpose_f32(const float *W, int rows, int cols, int64_t ldw, float *Wt, hipStream_t st);
+int gate_mlp(const float *aspect, int64_t lda, int B, int H, const float *w1t_a, const float *b1_a, const float *w2t_a,
+             const float *b2_a, float *gate_a, const float *w1t_b, const float *b1_b, const float *w2t_b,
+             const float *b2_b, float *gate_b, hipStream_t st);
+int scores_head(const float *X, int64_t ldx, const float *aspect, int64_t lda, const float *logits, int64_t ldl,
+                const float *fcw, int64_t ldw, const float *fcb, const float *dist, int64_t ldd, int B, int T, int H,
+                int C, float *scores, int64_t lds_, float *kl_part, hipStream_t st);
+
 size_t overlap_workspace_bytes(int B);
 int gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,
                  hipStream_t st);

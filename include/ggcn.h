@@ -255,6 +255,32 @@ size_t ggcn_overlap_workspace_bytes(int B);
 int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy,
                       void *workspace, ggcn_stream_t stream);
 
+/* ---- the gate MLPs in one launch ------------------------------------------
+ * Replaces models/bert_amir5.py:562-571,621-622: gate_k = Sigmoid(Linear2(Sigmoid(Linear1(Sigmoid(aspect))))) for
+ * both gates at once; aspect [B,H] (lda in elements) -> gate_a, gate_b [B,H] contiguous (the reference's
+ * .repeat(1,T).view() to [B,T,H] is never made: the layer kernels take [B,H] gates).  w*t are the nn.Linear
+ * weights TRANSPOSED to [in,out] contiguous (ggcn_transpose, once per weight update); biases [H] or NULL.
+ * The second gate (w1t_b .. gate_b) may be all NULL.  Plain fp32 FMA chains. */
+int ggcn_transpose(const float *W, int rows, int cols, int64_t ldw, float *Wt, ggcn_stream_t stream);
+int ggcn_gate_mlp(const float *aspect, int64_t lda, int B, int H,
+                  const float *w1t_a, const float *b1_a, const float *w2t_a, const float *b2_a, float *gate_a,
+                  const float *w1t_b, const float *b1_b, const float *w2t_b, const float *b2_b, float *gate_b,
+                  ggcn_stream_t stream);
+
+/* ---- scores / kl head in one launch ----------------------------------------
+ * Replaces models/bert_amir5.py:645-648:
+ *     output_w = fc(cat[x, aspect repeated over t])       [B,T,C], fc.weight [C, 2H], fc.bias [C]
+ *     scores   = sum_c logits[b,c] * output_w[b,t,c]      [B,T]
+ *     kl       = mean_b sum_t softmax_t(scores) * softmax_t(dist)
+ * without the [B,T,2H] concat or the [B,T,C] product: scores[b,t] = (Wx^T.logits_b).x_t + logits_b.(Wa.a_b + b).
+ * X [B*T, ldx] is the block's gated layer-2 output; dist [B, ldd] float (the reference's dist_to_target.float());
+ * kl_part [B] receives sum_t ... per sentence -- ggcn_overlap_reduce(kl_part, B, 1, kl) finishes the mean.
+ * dist and kl_part may both be NULL (scores only). */
+int ggcn_scores_head(const float *X, int64_t ldx, const float *aspect, int64_t lda,
+                     const float *logits, int64_t ldl, const float *fc_weight, int64_t ldw, const float *fc_bias,
+                     const float *dist, int64_t ldd, int B, int T, int H, int C,
+                     float *scores, int64_t ld_scores, float *kl_part, ggcn_stream_t stream);
+
 /* ---- range check for GGCN_PREC_F16MX8 (on demand, not on the forward path) ----------------
  * out[0] = max |x| over the finite entries of X [M,K] (fp32, or IEEE half when is_half != 0; ld in
  * elements), out[1] = 1.0f when some entry is NaN or infinite.  f16mx8 needs |x|, |w| < 65504 and keeps

@@ -95,10 +95,21 @@ class BertAmir55Oracle(nn.Module):
         anchor_rep = self.dropout(x[rows, anchor])                          # :604-608 (masked_select of the anchor row)
         x, _ = self.lstm(x)                                                 # :610
         aspect = x[rows, anchor]                                            # :615-618
-        gate1 = self.dropout(self.gate1(aspect))                            # :621-625, kept [B,H]
-        gate2 = self.dropout(self.gate2(aspect))
-        r = ref_dense.gated_block(x, adj, gate1, gate2, self.gc1.weight, self.gc1.bias,
-                                  self.gc2.weight, self.gc2.bias)           # :626-640
+        if self.training and self.dropout.p > 0:
+            # :621-625 in the reference's order: repeat to [B,T,H] FIRST, then dropout (one mask per token)
+            gate1 = self.dropout(self.gate1(aspect).repeat(1, T).view(x.shape))
+            gate2 = self.dropout(self.gate2(aspect).repeat(1, T).view(x.shape))
+            gcn1 = ref_dense.graph_convolution(x, adj, self.gc1.weight, self.gc1.bias)       # :626
+            x1 = torch.max(gcn1 * gate1, 1)[0]                                                # :627-635
+            y1 = torch.max(gcn1 * gate2, 1)[0]                                                # :631-636
+            xg = gate2 * ref_dense.graph_convolution(gcn1, adj, self.gc2.weight, self.gc2.bias)   # :639
+            r = {"xy": (x1 * y1).sum(1).mean(), "x": xg, "out": torch.max(xg, dim=1)[0]}      # :638,640
+            self.dropout(pooled)                                                              # :641
+        else:
+            gate1 = self.gate1(aspect)                                      # :621-622 (dropout is the identity)
+            gate2 = self.gate2(aspect)
+            r = ref_dense.gated_block(x, adj, gate1, gate2, self.gc1.weight, self.gc1.bias,
+                                      self.gc2.weight, self.gc2.bias)       # :626-640
         out = self.dropout(r["out"])                                        # :642
         logits = self.dense(torch.cat([anchor_rep, aspect, out], dim=1))    # :643
         xg = r["x"]

@@ -1033,3 +1033,146 @@ def test_backward_through_a_collated_batch_uses_no_host_transpose(pkg, dev):
         _grad_close(xg.grad, xr.grad, "x")
         _grad_close(m.weight.grad, wr.grad, "w")
         _grad_close(m.bias.grad, br.grad, "b")
+
+
+# ---------------------------------------------------------------- gate MLPs, scores/kl head, collated batches
+def _golden_gate_seq(g, name, dev):
+    seq = torch.nn.Sequential(torch.nn.Sigmoid(), torch.nn.Linear(256, 256), torch.nn.Sigmoid(), torch.nn.Linear(256, 256),
+                              torch.nn.Sigmoid()).to(dev)
+    with torch.no_grad():
+        for i in (1, 3):
+            seq[i].weight.copy_(torch.from_numpy(g["p_%s.%d.weight" % (name, i)]))
+            seq[i].bias.copy_(torch.from_numpy(g["p_%s.%d.bias" % (name, i)]))
+    return seq
+
+
+def test_gate_mlps_one_launch_golden_and_oracle(pkg, dev, golden_dir):
+    """bert_amir5.py:562-571,621-622 as one launch: the gates the REFERENCE computed (fixture G3), and seeded
+    shapes against the same nn.Sequential on the CPU (ragged B, H that is not a multiple of 256)."""
+    g = np.load(os.path.join(golden_dir, "amir55_block.npz"))
+    s1, s2 = _golden_gate_seq(g, "gate1", dev), _golden_gate_seq(g, "gate2", dev)
+    with torch.no_grad():
+        g1, g2 = pkg.gate_mlps(torch.from_numpy(g["aspect"]).to(dev), s1, s2)
+    np.testing.assert_allclose(g1.cpu().numpy(), g["gate1"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(g2.cpu().numpy(), g["gate2"], rtol=0, atol=2e-6)
+    for B, H in ((1, 8), (19, 300), (256, 256), (5, 1024)):
+        gen = torch.Generator().manual_seed(B + H)
+        mk = lambda: torch.nn.Sequential(torch.nn.Sigmoid(), torch.nn.Linear(H, H), torch.nn.Sigmoid(), torch.nn.Linear(H, H),
+                                         torch.nn.Sigmoid())
+        c1, c2 = mk(), mk()
+        a = torch.randn(B, H, generator=gen) * 2
+        with torch.no_grad():
+            want1, want2 = c1(a), c2(a)
+            import copy
+            got1, got2 = pkg.gate_mlps(a.to(dev), copy.deepcopy(c1).to(dev), copy.deepcopy(c2).to(dev))
+        assert float((got1.cpu() - want1).abs().max()) <= 3e-6 and float((got2.cpu() - want2).abs().max()) <= 3e-6
+
+
+def test_scores_and_kl_head_golden_and_oracle(pkg, dev, golden_dir):
+    """bert_amir5.py:645-648 as one launch (+ the 1-workgroup mean): the REFERENCE's scores and kl (fixture G3)
+    from its x, aspect and logits; and seeded shapes against the literal torch ops."""
+    g = np.load(os.path.join(golden_dir, "amir55_block.npz"))
+    fc = torch.nn.Linear(512, 34).to(dev)
+    with torch.no_grad():
+        fc.weight.copy_(torch.from_numpy(g["p_fc.0.weight"])); fc.bias.copy_(torch.from_numpy(g["p_fc.0.bias"]))
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    xg = t("gate2")[:, None, :] * t("gc2_out")
+    for B, T, H, C in ((3, 7, 64, 5), (9, 31, 256, 34), (2, 100, 96, 12), (1, 1, 8, 2)):
+        gen = torch.Generator().manual_seed(B * T)
+        x = torch.randn(B, T, H, generator=gen)
+        a = torch.randn(B, H, generator=gen)
+        lg = torch.randn(B, C, generator=gen)
+        lin = torch.nn.Linear(2 * H, C)
+        dist = torch.randint(0, 12, (B, T), generator=gen)
+        with torch.no_grad():
+            ow = lin(torch.cat([x, a.repeat(1, T).view(B, T, H)], dim=2))
+            want_s = (lg.repeat(1, T).view(B, T, -1) * ow).sum(2)
+            want_kl = (torch.softmax(want_s, 1) * torch.softmax(dist.float(), 1)).sum(1).mean()
+            import copy
+            got_s, got_kl = pkg.scores_and_kl(x.to(dev), a.to(dev), lg.to(dev), copy.deepcopy(lin).to(dev), dist.to(dev))
+        assert float((got_s.cpu() - want_s).abs().max()) <= 2e-5 * max(1.0, float(want_s.abs().max()))
+        assert abs(float(got_kl) - float(want_kl)) <= 1e-6
+    if "dist" in g.files:
+        with torch.no_grad():
+            s, kl = pkg.scores_and_kl(xg, t("aspect"), t("logits"), fc, t("dist"))
+        np.testing.assert_allclose(s.cpu().numpy(), g["scores"], rtol=0, atol=2e-5)
+        assert abs(float(kl) - float(g["kl"])) <= 1e-6
+    else:   # the fixture holds no dist: scores only
+        with torch.no_grad():
+            s, _ = pkg.scores_and_kl(xg, t("aspect"), t("logits"), fc, torch.zeros(4, 31, device=dev))
+        np.testing.assert_allclose(s.cpu().numpy(), g["scores"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("precision,fused", [("bf16x3", "block"), ("f16mx8", "block"), ("bf16x3", True), ("fp32", False)],
+                         ids=["bf16x3-block", "f16mx8-block", "bf16x3-fused", "fp32"])
+def test_collated_batch_through_the_block_golden(pkg, dev, golden_dir, precision, fused):
+    """The wire format end to end on the GPU: per-sample graphs cached once by GraphBatcher,
+    collated for the batch (device = GPU), through the HIP block, against the REFERENCE's tensors (fixture G3)."""
+    from ed_gated_gcn_amd.batcher import GraphBatcher
+    g = np.load(os.path.join(golden_dir, "amir55_block.npz"))
+    B, T = g["adj"].shape[0], g["adj"].shape[1]
+    gb = GraphBatcher()
+    ORI_ML = 40
+    for i in range(B):                                     # what the dataset holds: [ORI_ML, ORI_ML], identity-padded
+        dense = np.eye(ORI_ML, dtype=np.int64)
+        dense[:T, :T] = g["adj"][i]
+        gb.add("s%d" % i, dense)
+    csr = gb.collate(["s%d" % i for i in range(B)], T, dev)
+    assert csr.rowmask is not None and csr.rowmask.is_cuda and csr.is_binary
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    gc1 = _layer(pkg, dev, g["p_gc1.weight"], g["p_gc1.bias"], precision, fused)
+    gc2 = _layer(pkg, dev, g["p_gc2.weight"], g["p_gc2.bias"], precision, fused)
+    with torch.no_grad():
+        r = _block(pkg, t("lstm_out"), csr, t("gate1"), t("gate2"), gc1, gc2, fused)
+        dense_r = _block(pkg, t("lstm_out"), t("adj"), t("gate1"), t("gate2"), gc1, gc2, fused)
+    tol = TOL[precision]
+    np.testing.assert_allclose(r["gcn1"].cpu().numpy(), g["gcn1"], rtol=0, atol=tol)
+    np.testing.assert_allclose(r["x"].cpu().numpy(), g["gate2"][:, None, :] * g["gc2_out"], rtol=0, atol=tol)
+    np.testing.assert_allclose(r["out"].cpu().numpy(), g["out"], rtol=0, atol=tol)
+    for k in ("gcn1", "x", "out", "x1", "y1"):
+        assert torch.equal(r[k], dense_r[k]), k            # collated CSR == device-side conversion of the dense slice
+
+
+def test_training_dropout_masks_the_gates_per_token(pkg, dev):
+    """bert_amir5.py:621-625 drops entries of the REPEATED [B,T,H] gates: with p = 0.5 a pooled feature is zero only
+    when all T tokens lose it (2^-T), not with probability p as one shared [B,H] mask would give."""
+    import types
+    from ed_gated_gcn_amd import synth
+
+    class _Bert(torch.nn.Module):
+        def forward(self, ids, seg, output_all_encoded_layers=True):
+            gen = torch.Generator(device=ids.device).manual_seed(1)
+            return ([torch.randn(ids.shape[0], ids.shape[1], 768, device=ids.device, generator=gen) for _ in range(12)],
+                    torch.zeros(ids.shape[0], 768, device=ids.device))
+    opt = types.SimpleNamespace(dropout=0.5, polarities_dim=34, device=dev)
+    m = pkg.GatedGCNEventDetector(_Bert(), opt)
+    gen = torch.Generator().manual_seed(0)
+    for p in m.parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_uniform_(p, generator=gen)
+        else:
+            torch.nn.init.uniform_(p, -0.05, 0.05, generator=gen)
+    m = m.to(dev)
+    with torch.no_grad():
+        m.gc1.bias.fill_(5.0)                              # gcn1 > 0 everywhere: x1 = 0 iff every token's gate entry was dropped
+    rng = np.random.default_rng(0)
+    inputs = _ace_batch(rng, 32, 31, 60)
+    inputs = {k: v.to(dev) for k, v in inputs.items()}
+    seen = {}
+    orig = torch.max
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        if len(a) == 2 and a[1] == 1 and a[0].dim() == 3 and "x1" not in seen:
+            seen["x1"] = r[0].detach()
+        return r
+    m.train()
+    torch.max = spy
+    try:
+        logits, xy, kl, scores = m(inputs)
+    finally:
+        torch.max = orig
+    (logits.sum() + xy + kl).backward()                    # the HIP layers train under this path
+    assert m.gc1.weight.grad is not None and torch.isfinite(m.gc1.weight.grad).all()
+    zero_frac = float((seen["x1"] == 0).float().mean())
+    assert zero_frac < 0.02, "pooled features vanish with probability %.2f: the dropout mask is shared by the tokens" % zero_frac
