@@ -150,8 +150,18 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int kq = s_k + 4 * q;  // k offset inside the 32-deep stage
+            // Both planes take ONE 8-byte store per lane (16 lanes = 2 rows = 32 banks: conflict-free).  The q pair
+            // is stored by an asm ds_write_b64: l8 and h8 come out of the converts in unrelated registers and
+            // hipcc then prefers ds_write2_b32, whose 32-lane groups span 4 rows = 64 dwords on 32 banks (2-way
+            // conflicts: SQ_LDS_BANK_CONFLICT 12 % of the LDS cycles, round-2 PMC).  The asm store is issued
+            // BEFORE the compiler-tracked h store: LDS operations complete in order, so every lgkmcnt wait that
+            // covers the h store (the stage's barrier) covers this one too.
+            {
+                const uint64_t pair = ((uint64_t)(uint32_t)sp[q].h8 << 32) | (uint32_t)sp[q].l8;
+                const uint32_t addr = (uint32_t)(uintptr_t)(q_plane + a_lds_off(row, kq >> 3) + (kq & 4) * 2);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(pair) : "memory");
+            }
             *reinterpret_cast<uint2 *>(h_plane + a_lds_off(row, kq >> 3) + (kq & 4) * 2) = make_uint2(sp[q].h01, sp[q].h23);
-            *reinterpret_cast<uint2 *>(q_plane + a_lds_off(row, kq >> 3) + (kq & 4) * 2) = make_uint2((uint32_t)sp[q].l8, (uint32_t)sp[q].h8);
         }
     };
 
