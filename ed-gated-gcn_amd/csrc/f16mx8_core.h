@@ -26,9 +26,10 @@
 // needs |x| < 65504: this mode is for activations of ordinary magnitude (LSTM / GCN outputs);
 // bf16x3 keeps the full fp32 range.
 //
-// LDS per stage and buffer: plane 0 = xh as fp16 [128 rows][64 B], plane 1 = per 4 k the 8 bytes
-// {xl8 x4, xh8 x4} -- 128 B per row like bf16x3, same XOR chunk swizzle, same conflict-free reads
-// (the MX operand's dword order is restored for free when the two 16-byte reads are assembled).
+// LDS per stage and buffer: plane 0 = xh as fp16 [128 rows][64 B], plane 1 = per row [xl8 of lane half 0 |
+// xl8 of lane half 1 | xh8 of half 0 | xh8 of half 1], 16 B each, in the k order of the fp16 fragments --
+// 128 B per row like bf16x3, same XOR chunk swizzle, same conflict-free reads; the MX operand is two plain
+// 16-byte reads.
 // Packed weight per (32-column tile, 32-deep stage): [f16 frag k-step 0: 1 KiB][k-step 1: 1 KiB]
 // [fp8(wl * 2^s1): 64 lanes x 16 B][scales: 64 lanes x 4 B] = 3328 B.  The other half of the MX
 // operand, fp8(wh * 2^s0), is NOT stored: every lane converts the 16 fp16 values of its two fragments
@@ -150,18 +151,12 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int kq = s_k + 4 * q;  // k offset inside the 32-deep stage
-            // Both planes take ONE 8-byte store per lane (16 lanes = 2 rows = 32 banks: conflict-free).  The q pair
-            // is stored by an asm ds_write_b64: l8 and h8 come out of the converts in unrelated registers and
-            // hipcc then prefers ds_write2_b32, whose 32-lane groups span 4 rows = 64 dwords on 32 banks (2-way
-            // conflicts: SQ_LDS_BANK_CONFLICT 12 % of the LDS cycles, round-2 PMC).  The asm store is issued
-            // BEFORE the compiler-tracked h store: LDS operations complete in order, so every lgkmcnt wait that
-            // covers the h store (the stage's barrier) covers this one too.
-            {
-                const uint64_t pair = ((uint64_t)(uint32_t)sp[q].h8 << 32) | (uint32_t)sp[q].l8;
-                const uint32_t addr = (uint32_t)(uintptr_t)(q_plane + a_lds_off(row, kq >> 3) + (kq & 4) * 2);
-                asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(pair) : "memory");
-            }
             *reinterpret_cast<uint2 *>(h_plane + a_lds_off(row, kq >> 3) + (kq & 4) * 2) = make_uint2(sp[q].h01, sp[q].h23);
+            // q plane: 16-byte chunk hh = the four xl8 dwords lane half hh reads (k = 8hh..8hh+7, 16+8hh..16+8hh+7),
+            // chunk 2+hh = its four xh8 dwords -- the MX operand's two scale blocks are two plain 16-byte reads
+            const int g = kq >> 2, hh = (g >> 1) & 1, pos = (g & 1) + 2 * (g >> 2);
+            *reinterpret_cast<uint32_t *>(q_plane + a_lds_off(row, hh) + 4 * pos) = (uint32_t)sp[q].l8;
+            *reinterpret_cast<uint32_t *>(q_plane + a_lds_off(row, 2 + hh) + 4 * pos) = (uint32_t)sp[q].h8;
         }
     };
 
@@ -221,11 +216,13 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     auto read_q = [&](int buf, int i, i32x8 &a) {
         const char *q_plane = lds + buf * (2 * BM * ROWB) + BM * ROWB;
         const int row = f_row + i * 32;
-        // k = 8h..8h+7 and 16+8h..16+8h+7 (the k of this lane half's fp16 fragments) as {xl8 x4, xh8 x4}
-        // groups: even dwords -> block 0 (xl), odd dwords -> block 1 (xh)
+        // chunk h: xl8 of k = 8h..8h+7, 16+8h..16+8h+7 (scale block 0); chunk 2+h: xh8 of the same k (block 1).
+        // The dwords arrive in operand order: no register shuffle sits between the reads and the MFMA, so the
+        // reads' latency hides behind the MFMAs issued before their first use.  (The earlier {xl8,xh8} pair
+        // layout needed 8 moves per operand right behind the reads: an exposed LDS round trip four times a stage.)
         const i32x4 lo = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, f_half));
         const i32x4 hi = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, 2 + f_half));
-        a = i32x8{lo[0], lo[2], hi[0], hi[2], lo[1], lo[3], hi[1], hi[3]};
+        a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
 #pragma unroll
