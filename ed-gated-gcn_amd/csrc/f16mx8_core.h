@@ -75,10 +75,13 @@ __device__ __forceinline__ Split4 split4(float x0, float x1, float x2, float x3)
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(p1), "v"(x2));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(p1), "v"(x3));
     constexpr float inv = 1.0f / (float)(1 << XL_SHIFT);
-    s2 q = {0, 0};
+    // the packed converts write HALF of their destination and keep the other half: the value the destination
+    // starts with is irrelevant (both halves get written), so it is seeded with a register that dies here
+    // instead of a zero -- a zero costs one v_mov per destination, 16 of the ~90 VALU of a stage
+    s2 q = __builtin_bit_cast(s2, r0);
     q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, r0, r1, inv, false);
     q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, r2, r3, inv, true);
-    int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, 0, false);
+    int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, __builtin_bit_cast(int, x0), false);
     h8 = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, h8, true);
     Split4 o;
     o.h01 = __builtin_bit_cast(uint32_t, p0);
@@ -196,7 +199,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         for (int d = 0; d < 4; ++d) {
             const f16x8 &f = d < 2 ? f0 : f1;
             const int e = (d & 1) * 4;
-            s2 q = {0, 0};
+            s2 q = __builtin_bit_cast(s2, h2{f[e], f[e + 1]});   // seed: a register that dies here (see split4)
             q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, h2{f[e], f[e + 1]}, inv, false);
             q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, h2{f[e + 2], f[e + 3]}, inv, true);
             o[d] = __builtin_bit_cast(int, q);

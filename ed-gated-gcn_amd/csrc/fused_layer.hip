@@ -118,7 +118,7 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
 template <int SCH, bool AVEC, bool KFULL, bool FULLT, bool VST>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(const FusedArgs a)
 {
-    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes + GGCN_LAB_LDS_PAD];
     const int B = a.B, T = a.T, K = a.K, F = a.F;
     // bert_amir5.py:638 for the launch BEFORE this one on the stream: block 0 adds the per-(graph,
     // 64-column group) partial dot products that launch left in ov_in, in a fixed order
@@ -223,8 +223,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
     // the A buffers are free after the main loop's last barrier: 8 KiB per wavefront = 32 rows x 64 columns
     float *stage_lds = reinterpret_cast<float *>(lds) + wave * (32 * 64);
     const int perm_base = 16 * h;          // ds_bpermute byte address of lane 4h (+ 4*row0 per register)
-    const bool vst = VST && out != nullptr;  // workgroup-uniform
-
+    // The graph loop exists twice, with and without the [N,F] output: `out` is workgroup-uniform (NULL for the
+    // W1 tiles of the block), and a test of it inside the element loop puts a scalar branch around every one of a
+    // tile's 16 staging stores -- 16 basic blocks per tile that nothing can be scheduled across.
+    auto graphs = [&](auto has_out) {
+    constexpr bool vst = VST && decltype(has_out)::value;
+    constexpr bool direct_store = !VST && decltype(has_out)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int g = g0 + i;
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
                     stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = v * sg;
                 }
                 if (FULLT || row0 + 4 * h < T) {
-                    if (!VST && tile && col_ok[j]) tile[lane_off + row0 * ldo] = v * sg;  // bert_amir5.py:626 / :639
+                    if (direct_store && col_ok[j]) tile[lane_off + row0 * ldo] = v * sg;  // bert_amir5.py:626 / :639
                     vmax = fmaxf(vmax, v);
                     vmin = fminf(vmin, v);
                 }
@@ -322,6 +326,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
         }
         if (i == 0) GGCN_TRACE(7);
     }
+    };
+    if (out) graphs(std::true_type{});
+    else graphs(std::false_type{});
     GGCN_TRACE(6);
 }
 

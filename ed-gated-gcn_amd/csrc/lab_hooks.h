@@ -2,6 +2,11 @@
 // In the product build every hook below is empty: nothing here changes a product kernel.
 #pragma once
 
+// occupancy experiments: extra static LDS per workgroup (0 in the product build)
+#ifndef GGCN_LAB_LDS_PAD
+#define GGCN_LAB_LDS_PAD 0
+#endif
+
 #ifdef GGCN_LAB_TRACE
 // timeline probe: per workgroup {block, HW_ID, XCC_ID, t_start, t_loop_begin, t_loop_end, t_end} in 10 ns ticks
 __device__ unsigned long long ggcn_trace_buf[8192 * 8];
