@@ -83,6 +83,13 @@ __device__ __forceinline__ void split2(const f32x16 &acc, bf16x8 (&frag)[2][2])
         }
 }
 
+// lanes 0-31 receive the value of lane + 32 (lanes 32-63: unspecified, their own lower-half partner's value)
+__device__ __forceinline__ float upper_half_to_lower(float v)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[1]);   // r[1] = the "src" operand after the swap: its lanes 0-31 hold v of lanes 32-63
+}
+
 // ADJ_g . t for one 32x32 tile: 4 MFMAs (2 planes x 2 k-steps), small plane first
 __device__ __forceinline__ f32x16 adj_times(const bf16x8 (&af)[2], const f32x16 &t)
 {
@@ -292,8 +299,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
                     vmin = fminf(vmin, v);
                 }
             }
-            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
-            vmin = fminf(vmin, __shfl_xor(vmin, 32));
+            // the other lane half's value: v_permlane32_swap (one VALU instruction; __shfl_xor(.., 32) is a
+            // ds_bpermute, an LDS round trip in front of the pooled stores).  Only lanes 0-31 use the result.
+            vmax = fmaxf(vmax, upper_half_to_lower(vmax));
+            vmin = fminf(vmin, upper_half_to_lower(vmin));
             if (h == 0 && col_ok[j]) {
                 const float ga = pool_gate_a ? vga[i][j] : 1.0f, gb = pool_gate_b ? vgb[i][j] : 1.0f;
                 const float pa = ga * (ga >= 0.0f ? vmax : vmin), pb = gb * (gb >= 0.0f ? vmax : vmin);
