@@ -23,6 +23,7 @@ _ADJ_DTYPES = {
 # `adj` (models/bert_amir5.py:589,626,639) and share one conversion -- and one read-back of the weighted flag.
 _RECENT = []
 _RECENT_MAX = 4
+MASK_MAX_T = 128   # include/ggcn.h GGCN_MASK_MAX_T: largest graph the row-mask (one-launch layer) path takes
 
 
 def cached_from_dense(adj, binary=None):
@@ -38,9 +39,10 @@ def cached_from_dense(adj, binary=None):
 
 class BatchedCSR:
     """rowptr int32[N+1], colidx int32[cap], vals fp32[cap] or None (binary adjacency),
-    rowmask uint32-as-int32[N] or None (T <= 32: bit j of word i = edge i<-j), on one GPU.
+    rowmask uint32-as-int32[N * ceil(T/32)] or None (T <= MASK_MAX_T = 128: bit j%32 of word j/32 of node i =
+    edge i<-j), on one GPU.
 
-    Built from a dense adjacency with T <= 32 only the row masks are computed up front (one
+    Built from a dense adjacency with T <= 128 only the row masks are computed up front (one
     kernel: all the fused layer needs); the CSR arrays are materialised on first access."""
 
     __slots__ = ("_rowptr", "_colidx", "_vals", "rowmask", "B", "T", "nnz", "is_binary",
@@ -131,8 +133,8 @@ class BatchedCSR:
         sb, sr, sc = adj.stride()
         out = cls(None, None, None, B, T)
         out._dense, out._dense_version = adj, adj._version
-        if T <= 32:
-            out.rowmask = torch.empty(n, dtype=torch.int32, device=dev)
+        if T <= MASK_MAX_T:
+            out.rowmask = torch.empty(n * ((T + 31) // 32), dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.ggcn_rowmask_from_dense(_capi.ptr(adj), _ADJ_DTYPES[adj.dtype], B, T, sb, sr, sc,
                                                  _capi.ptr(out.rowmask), _capi.ptr(flags), _capi.stream_of(dev))
@@ -174,9 +176,11 @@ class BatchedCSR:
         if vals is not None and not np.all(np.asarray(vals) == 1):
             v = torch.from_numpy(np.ascontiguousarray(vals, dtype=np.float32)).to(device)
         mask = None
-        if T <= 32:  # 0/1 adjacency words for the fused layer kernel
-            m = np.zeros(B * T, dtype=np.uint32)
-            np.bitwise_or.at(m, rows, (np.uint32(1) << (colidx.astype(np.int64) % T).astype(np.uint32)))
+        if T <= MASK_MAX_T:  # 0/1 adjacency words for the fused layer kernel: ceil(T/32) words per node
+            W = (T + 31) // 32
+            m = np.zeros(B * T * W, dtype=np.uint32)
+            local = colidx.astype(np.int64) % T
+            np.bitwise_or.at(m, rows * W + local // 32, (np.uint32(1) << (local % 32).astype(np.uint32)))
             mask = torch.from_numpy(m.view(np.int32)).to(device)
         out = cls(torch.from_numpy(rowptr).to(device), torch.from_numpy(colidx).to(device), v, B, T,
                   nnz=int(colidx.shape[0]), rowmask=mask)

@@ -50,8 +50,12 @@ __global__ __launch_bounds__(256) void csr_walk_rows(
         const unsigned long long m = __ballot(nz);
         if (FILL) {
             weighted |= nz && (v != 1.0f);
-            // T <= 32: the ballot IS the row's 0/1 adjacency word (bit j = edge i<-j)
-            if (rowmask && j0 == 0 && lane == 0) rowmask[row] = (uint32_t)m;
+            // the ballot IS 64 bits of the row's 0/1 adjacency (bit j = edge i<-j): ceil(T/32) words per row
+            if (rowmask && lane == 0) {
+                const int W = (T + 31) >> 5;
+                rowmask[row * W + (j0 >> 5)] = (uint32_t)m;
+                if (j0 + 32 < T) rowmask[row * W + (j0 >> 5) + 1] = (uint32_t)(m >> 32);
+            }
         }
         if (FILL && nz) {
             const int64_t pos = base + cnt + __popcll(m & ((1ull << lane) - 1ull));
@@ -164,14 +168,45 @@ __global__ __launch_bounds__(256) void rowmask_rows(const A *__restrict__ adj, i
     if (flags && __any(v != 0.0f && v != 1.0f) && lane == 0) atomicOr(flags, GGCN_FLAG_WEIGHTED);
 }
 
+// Row masks for 32 < T <= 128: one wavefront per row, 64 columns per ballot, ceil(T/32) words per row.
+template <typename A>
+__global__ __launch_bounds__(256) void rowmask_rows_wide(const A *__restrict__ adj, int64_t n_rows, int T,
+                                                         int64_t sb, int64_t sr, int64_t sc,
+                                                         uint32_t *__restrict__ rowmask, int32_t *__restrict__ flags)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int64_t b = row / T;
+    const int i = (int)(row - b * T);
+    const A *r = adj + b * sb + (int64_t)i * sr;
+    const int W = (T + 31) >> 5;
+    bool weighted = false;
+    for (int j0 = 0; j0 < T; j0 += kWave) {
+        const int j = j0 + lane;
+        const float v = (j < T) ? load_adj<A>(r + (int64_t)j * sc) : 0.0f;
+        weighted |= (v != 0.0f) && (v != 1.0f);
+        const unsigned long long m = __ballot(v != 0.0f);
+        if (lane == 0) {
+            rowmask[row * W + (j0 >> 5)] = (uint32_t)m;
+            if (j0 + 32 < T) rowmask[row * W + (j0 >> 5) + 1] = (uint32_t)(m >> 32);
+        }
+    }
+    if (flags && __any(weighted) && lane == 0) atomicOr(flags, GGCN_FLAG_WEIGHTED);
+}
+
 template <typename A>
 int run_mask(const void *adj, int B, int T, int64_t sb, int64_t sr, int64_t sc, uint32_t *rowmask,
              int32_t *flags, hipStream_t st)
 {
     const int64_t n = (int64_t)B * T;
     if (flags) (void)hipMemsetAsync(flags, 0, sizeof(int32_t), st);
-    hipLaunchKernelGGL((rowmask_rows<A>), dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st,
-                       static_cast<const A *>(adj), n, T, sb, sr, sc, rowmask, flags);
+    if (T <= 32)
+        hipLaunchKernelGGL((rowmask_rows<A>), dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st,
+                           static_cast<const A *>(adj), n, T, sb, sr, sc, rowmask, flags);
+    else
+        hipLaunchKernelGGL((rowmask_rows_wide<A>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st,
+                           static_cast<const A *>(adj), n, T, sb, sr, sc, rowmask, flags);
     return check_launch("ggcn_rowmask_from_dense");
 }
 
@@ -267,7 +302,8 @@ int rowmask_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb,
 {
     if (!adj || !rowmask) return fail(GGCN_EINVAL, "ggcn_rowmask_from_dense: null pointer");
     if (B <= 0 || T <= 0) return fail(GGCN_EINVAL, "ggcn_rowmask_from_dense: B=%d T=%d must be positive", B, T);
-    if (T > 32) return fail(GGCN_EUNSUPPORTED, "ggcn_rowmask_from_dense: row masks need T <= 32, got T=%d", T);
+    if (T > GGCN_MASK_MAX_T)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_rowmask_from_dense: row masks need T <= %d, got T=%d", GGCN_MASK_MAX_T, T);
     switch (adj_dtype) {
         case GGCN_ADJ_F32: return run_mask<float>(adj, B, T, sb, sr, sc, rowmask, flags, st);
         case GGCN_ADJ_U8: return run_mask<uint8_t>(adj, B, T, sb, sr, sc, rowmask, flags, st);
@@ -283,8 +319,8 @@ int csr_from_dense(const void *adj, int adj_dtype, int B, int T, int64_t sb, int
                    int32_t *rowptr, int32_t *colidx, float *vals, int64_t capacity, uint32_t *rowmask,
                    int32_t *flags, void *workspace, hipStream_t st)
 {
-    if (rowmask && T > 32)
-        return fail(GGCN_EUNSUPPORTED, "ggcn_csr_from_dense: row masks need T <= 32, got T=%d", T);
+    if (rowmask && T > GGCN_MASK_MAX_T)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_csr_from_dense: row masks need T <= %d, got T=%d", GGCN_MASK_MAX_T, T);
     if (!adj || !rowptr || !colidx || !workspace)
         return fail(GGCN_EINVAL, "ggcn_csr_from_dense: null pointer");
     if (B <= 0 || T <= 0) return fail(GGCN_EINVAL, "ggcn_csr_from_dense: B=%d T=%d must be positive", B, T);

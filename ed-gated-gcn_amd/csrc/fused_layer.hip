@@ -90,6 +90,23 @@ __device__ __forceinline__ float upper_half_to_lower(float v)
     return __uint_as_float(r[1]);   // r[1] = the "src" operand after the swap: its lanes 0-31 hold v of lanes 32-63
 }
 
+// 0/1 adjacency block as the MFMA A operand: bit b of `m` (already shifted by 4h) -> element pairs of the two
+// k-steps; element j of k-step s is node 16s + 8(j>>2) + 4h + (j&3)
+__device__ __forceinline__ void expand_mask(uint32_t mh, bf16x8 (&af)[2])
+{
+    union { bf16x8 v; uint32_t w[4]; } u[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = 16 * s + 8 * (q >> 1) + 2 * (q & 1);
+            const uint32_t two = (mh >> b) & 3u;
+            u[s].w[q] = (two & 1u) * 0x3F80u + (two >> 1) * 0x3F800000u;  // bf16 1.0 = 0x3F80
+        }
+    af[0] = u[0].v;
+    af[1] = u[1].v;
+}
+
 // ADJ_g . t for one 32x32 tile: 4 MFMAs (2 planes x 2 k-steps), small plane first
 __device__ __forceinline__ f32x16 adj_times(const bf16x8 (&af)[2], const f32x16 &t)
 {
@@ -242,17 +259,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
         if (g >= B) break;  // workgroup-uniform
         // ---- adjacency fragments of graph g from this lane's row mask: element j of k-step s is
         // node 16s + 8(j>>2) + 4h + (j&3); two neighbouring elements = two neighbouring mask bits ----
-        const uint32_t mh = mask[i] >> (4 * h);
-        union { bf16x8 v; uint32_t w[4]; } af[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {  // element pair (2q, 2q+1): bits b, b+1 of mh
-                const int b = 16 * s + 8 * (q >> 1) + 2 * (q & 1);
-                const uint32_t two = (mh >> b) & 3u;
-                af[s].w[q] = (two & 1u) * 0x3F80u + (two >> 1) * 0x3F800000u;  // bf16 1.0 = 0x3F80
-            }
-        const bf16x8 afv[2] = {af[0].v, af[1].v};
+        bf16x8 afv[2];
+        expand_mask(mask[i] >> (4 * h), afv);
         // 1 / (rowsum(adj) + 1) of node lane&31 (gcn.py:35): one IEEE division per node, then the
         // value of row row0 + 4h is fetched per accumulator register through the LDS crossbar
         const float inv = 1.0f / (float)(__popc(mask[i]) + 1);
@@ -341,6 +349,201 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
     GGCN_TRACE(6);
 }
 
+// ---- graphs of 33..128 nodes (LitBank: ORI_ML = 100, constant.py:227) in the same one launch per layer ----
+// A graph occupies SB = 2 or 4 consecutive 32-row blocks of a wavefront's 128-row tile (64- or 128-row slot;
+// T in 65..96 takes the 128-row slot), its adjacency is SB x SB blocks of 32 x 32 bits (row masks of
+// ceil(T/32) words), and the neighbour sum of output block io is
+//     agg[io] = sum_ii ADJ[io][ii] . hidden[ii]          (SB x 4 MFMAs per 32 x 32 output tile)
+// with every hidden[ii] taken from the accumulator tiles as in the 32-node kernel.  All accumulators are first
+// split into their two bf16 planes IN PLACE (same register count), then each output block is produced,
+// normalised, gated, pooled and stored.  One part only (the two-layer block form stays with T <= 32).
+template <int SCH, bool AVEC, bool KFULL, bool VST, int SB>
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_wide_kernel(const FusedArgs a)
+{
+    static_assert(SB == 2 || SB == 4, "a graph slot is 64 or 128 rows");
+    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+    const int B = a.B, T = a.T, K = a.K, F = a.F;
+    if (a.ov_in && blockIdx.x == 0) reduce_partials(a.ov_in, B * ((F + 63) / 64), B, a.ov_out, reinterpret_cast<float *>(lds));
+    int g_tile, n_wgi;
+    if (!tile_of_block(blockIdx.x, a.g_tiles, a.n_wg, g_tile, n_wgi)) return;
+    const LayerPart &lp = a.part[0];
+    const float *__restrict__ bias = lp.bias, *__restrict__ store_gate = lp.store_gate;
+    const float *__restrict__ pool_gate_a = lp.pool_gate_a, *__restrict__ pool_gate_b = lp.pool_gate_b;
+    float *__restrict__ out = lp.out, *__restrict__ pool_a = lp.pool_a, *__restrict__ pool_b = lp.pool_b;
+    float *__restrict__ ov_partial = lp.ov_partial;
+    const int ldo = lp.ldo;
+    constexpr int S = 32 * SB, GPT = 4 / SB;      // rows per graph slot, graphs per wavefront tile
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    static_assert(WM == 1, "the wide-graph kernel is written for one wavefront row per workgroup");
+    const int g0 = g_tile * GPT;
+    const int n_tiles_total = (F + NT - 1) / NT;
+    const int nt0 = n_wgi * (BN / NT) + wn * RN;
+    const int W = (T + 31) >> 5;
+
+    constexpr int NP = Geom<float>::NP;
+    const float *arow[NP];
+    bool avalid[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int row = stage_row<float>(i);
+        const int g = g0 + row / S, r = row % S;
+        avalid[i] = (g < B) && (r < T);
+        const int64_t node = avalid[i] ? (int64_t)g * T + r : 0;
+        arow[i] = a.X + node * a.ldx;
+    }
+    f32x16 acc[4][RN];
+    if constexpr (SCH == 0)
+        bx3::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps, wm, nt0, n_tiles_total, lds, acc);
+    else
+        mx8::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
+
+    const int c = lane & 31, h = lane >> 5;
+    float vb[RN], vsg[GPT][RN], vga[GPT][RN], vgb[GPT][RN];
+    bool col_ok[RN];
+    {
+        const float *dummy = a.X;
+        const float *pb = bias ? bias : dummy, *psg = store_gate ? store_gate : dummy;
+        const float *pga = pool_gate_a ? pool_gate_a : dummy, *pgb = pool_gate_b ? pool_gate_b : dummy;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const int gn = (nt0 + j) * NT + c;
+            col_ok[j] = gn < F;
+            const int gnc = col_ok[j] ? gn : 0;
+            vb[j] = pb[bias ? gnc : 0];
+#pragma unroll
+            for (int s = 0; s < GPT; ++s) {
+                const int64_t at = (int64_t)(g0 + s < B ? g0 + s : 0) * F + gnc;
+                vsg[s][j] = psg[store_gate ? at : 0];
+                vga[s][j] = pga[pool_gate_a ? at : 0];
+                vgb[s][j] = pgb[pool_gate_b ? at : 0];
+            }
+        }
+    }
+    // every accumulator tile -> its two bf16 planes (B-operand fragments of the aggregation MFMAs), in place
+    bf16x8 hf[4][RN][2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) split2(acc[i][j], hf[i][j]);
+
+    float *stage_lds = reinterpret_cast<float *>(lds) + wave * (32 * 64);
+    const int perm_base = 16 * h;
+    const int lane_off = 4 * h * ldo + c;
+    auto graphs = [&](auto has_out) {
+        constexpr bool vst = VST && decltype(has_out)::value;
+        constexpr bool direct_store = !VST && decltype(has_out)::value;
+#pragma unroll
+        for (int s = 0; s < GPT; ++s) {
+            const int g = g0 + s;
+            if (g >= B) break;  // workgroup-uniform
+            // this lane's adjacency rows: node 32*io + (lane & 31), word ii, for the whole graph: one latency
+            uint32_t mw[SB][SB];
+#pragma unroll
+            for (int io = 0; io < SB; ++io) {
+                const int node = 32 * io + c;
+                const bool ok = node < T;
+#pragma unroll
+                for (int ii = 0; ii < SB; ++ii) {
+                    const bool okw = ok && ii < W;
+                    const uint32_t m = a.rowmask[okw ? ((int64_t)g * T + node) * W + ii : 0];
+                    mw[io][ii] = okw ? m : 0u;
+                }
+            }
+            float vmax[RN], vmin[RN];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) { vmax[j] = -INFINITY; vmin[j] = INFINITY; }
+#pragma unroll
+            for (int io = 0; io < SB; ++io) {
+                const int node0 = 32 * io;
+                if (node0 >= T) break;  // workgroup-uniform: block of padding rows
+                int deg = 0;
+                bf16x8 af[SB][2];
+#pragma unroll
+                for (int ii = 0; ii < SB; ++ii) {
+                    deg += __popc(mw[io][ii]);
+                    expand_mask(mw[io][ii] >> (4 * h), af[ii]);
+                }
+                const float inv = 1.0f / (float)(deg + 1);                  // gcn.py:35
+                float rinv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row0 = (r & 3) + 8 * (r >> 2);
+                    rinv[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_base + 4 * row0, __float_as_int(inv)));
+                }
+#pragma unroll
+                for (int j = 0; j < RN; ++j) {
+                    if (nt0 + j >= n_tiles_total) break;  // wavefront-uniform: column tile past F
+                    f32x16 y;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y[r] = 0.0f;
+#pragma unroll
+                    for (int p = 1; p >= 0; --p)  // small plane first
+#pragma unroll
+                        for (int ii = 0; ii < SB; ++ii)
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks)
+                                y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ii][ks], hf[s * SB + ii][j][p][ks], y, 0, 0, 0);   // gcn.py:41
+                    float *tile = decltype(has_out)::value ? out + ((int64_t)g * T + node0) * ldo + (nt0 + j) * NT : nullptr;
+                    const float sg = store_gate ? vsg[s][j] : 1.0f;
+                    const float bj = bias ? vb[j] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
+                        const float v = y[r] * rinv[r] + bj;      // gcn.py:41,43
+                        if (vst) stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = v * sg;
+                        if (node0 + row0 + 4 * h < T) {
+                            if (direct_store && col_ok[j]) tile[lane_off + row0 * ldo] = v * sg;
+                            vmax[j] = fmaxf(vmax[j], v);
+                            vmin[j] = fminf(vmin[j], v);
+                        }
+                    }
+                }
+                if (vst) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int colq = (lane & 15) * 4;
+                    const int gcol = nt0 * NT + colq;
+                    float *gbase = out + ((int64_t)g * T + node0) * ldo + gcol;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int row = 4 * it + (lane >> 4);
+                        const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 64 + (colq ^ (32 * ((row >> 2) & 1)))]);
+                        if (node0 + row < T && gcol < F) *reinterpret_cast<float4 *>(gbase + row * ldo) = v4;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            // pools of graph g: max over ALL its rows (bert_amir5.py:635-640), both gates from max and min of y
+            float dot = 0.0f;
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                if (nt0 + j >= n_tiles_total) break;
+                const float mx = fmaxf(vmax[j], upper_half_to_lower(vmax[j]));
+                const float mn = fminf(vmin[j], upper_half_to_lower(vmin[j]));
+                if (h == 0 && col_ok[j]) {
+                    const int gn = (nt0 + j) * NT + c;
+                    const float ga = pool_gate_a ? vga[s][j] : 1.0f, gb = pool_gate_b ? vgb[s][j] : 1.0f;
+                    const float pa = ga * (ga >= 0.0f ? mx : mn), pb = gb * (gb >= 0.0f ? mx : mn);
+                    if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
+                    if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
+                    dot = fmaf(pa, pb, dot);
+                }
+            }
+            if (ov_partial && nt0 < n_tiles_total) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
+                if (lane == 0) ov_partial[(int64_t)g * ((F + 63) / 64) + (nt0 >> 1)] = dot;
+            }
+        }
+    };
+    if (out) graphs(std::true_type{});
+    else graphs(std::false_type{});
+}
+
 // bert_amir5.py:638 after ggcn_block_fused: the per-(graph, 64-column group) partials -> one scalar.
 // One workgroup of 1024 threads, 16-byte loads with four independent sums per thread (config 2: 196 KB in
 // ~3 us; the 256-thread scalar loop took 67 us), fixed summation order: deterministic.
@@ -379,7 +582,7 @@ __global__ __launch_bounds__(kRedThreads) void overlap_reduce_kernel(const float
     }
 }
 
-// rowmask from a batched CSR (T <= 32): one thread per node
+// rowmask from a batched CSR (T <= GGCN_MASK_MAX_T): one thread per node, ceil(T/32) words each
 __global__ __launch_bounds__(256) void rowmask_kernel(const int32_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ colidx, int64_t n, int T,
                                                       uint32_t *__restrict__ rowmask)
@@ -387,9 +590,17 @@ __global__ __launch_bounds__(256) void rowmask_kernel(const int32_t *__restrict_
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int64_t base = i / T * T;
-    uint32_t m = 0;
-    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) m |= 1u << (uint32_t)(colidx[e] - base);
-    rowmask[i] = m;
+    const int W = (T + 31) >> 5;
+    uint32_t m[GGCN_MASK_MAX_T / 32] = {0u, 0u, 0u, 0u};
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+        const uint32_t j = (uint32_t)(colidx[e] - base);
+#pragma unroll
+        for (int w = 0; w < GGCN_MASK_MAX_T / 32; ++w)   // static indices: m stays in registers
+            if ((j >> 5) == (uint32_t)w) m[w] |= 1u << (j & 31u);
+    }
+#pragma unroll
+    for (int w = 0; w < GGCN_MASK_MAX_T / 32; ++w)
+        if (w < W) rowmask[i * W + w] = m[w];
 }
 
 // shared argument checks + launch of layer_fused_kernel for 1 or 2 parts
@@ -400,7 +611,10 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
     if (!a.X || !a.rowmask) return fail(GGCN_EINVAL, "%s: null input pointer", who);
     if (a.B <= 0 || a.T <= 0 || a.K <= 0 || a.F <= 0)
         return fail(GGCN_EINVAL, "%s: B=%d T=%d K=%d F=%d must be positive", who, a.B, a.T, a.K, a.F);
-    if (a.T > 32) return fail(GGCN_EUNSUPPORTED, "%s: T=%d > 32; use ggcn_linear + ggcn_aggregate", who, a.T);
+    if (a.T > GGCN_MASK_MAX_T)
+        return fail(GGCN_EUNSUPPORTED, "%s: T=%d > %d; use ggcn_linear + ggcn_aggregate", who, a.T, GGCN_MASK_MAX_T);
+    if (a.T > 32 && a.n_parts != 1)
+        return fail(GGCN_EUNSUPPORTED, "%s: the two-layer form takes graphs of <= 32 nodes (T=%d): one ggcn_layer_fused per layer", who, a.T);
     if (a.ldx < a.K) return fail(GGCN_EINVAL, "%s: ldx < K", who);
     bool vst = true, any_out = false;
     for (int p = 0; p < a.n_parts; ++p) {
@@ -420,8 +634,29 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
     const bool avec = (a.K % 4 == 0) && (a.ldx % 4 == 0) && aligned16(a.X);
     const bool kfull = (a.K % BK == 0);
     a.k_steps = round_up(a.K, BK) / KSTEP;
-    const int64_t g_tiles = ((int64_t)a.B + 4 * WM - 1) / (4 * WM);
     a.n_wg = (a.F + BN - 1) / BN;
+    if (a.T > 32) {   // 64- or 128-row graph slots: layer_fused_wide_kernel
+        const int sb = a.T <= 64 ? 2 : 4;
+        const int64_t gt = ((int64_t)a.B + 4 / sb - 1) / (4 / sb);
+        const int64_t gridw = grid_for(gt, a.n_wg);
+        if (gridw > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: batch too large", who);
+        a.g_tiles = (int)gt;
+        const bool fast = avec && kfull;
+#define GGCN_LAUNCHW(SC, AV, KF, VS, SBV) \
+    hipLaunchKernelGGL((layer_fused_wide_kernel<SC, AV, KF, VS, SBV>), dim3((unsigned)gridw), dim3(kThreads), 0, st, a)
+#define GGCN_PICKW(SC, SBV)                                              \
+    do {                                                                 \
+        if (fast && vst) GGCN_LAUNCHW(SC, true, true, true, SBV);        \
+        else if (fast) GGCN_LAUNCHW(SC, true, true, false, SBV);         \
+        else GGCN_LAUNCHW(SC, false, false, false, SBV);                 \
+    } while (0)
+        if (precision == GGCN_PREC_F16MX8) { if (sb == 2) GGCN_PICKW(1, 2); else GGCN_PICKW(1, 4); }
+        else { if (sb == 2) GGCN_PICKW(0, 2); else GGCN_PICKW(0, 4); }
+#undef GGCN_PICKW
+#undef GGCN_LAUNCHW
+        return check_launch(who);
+    }
+    const int64_t g_tiles = ((int64_t)a.B + 4 * WM - 1) / (4 * WM);
     const int64_t grid = a.n_parts == 1 ? grid_for(g_tiles, a.n_wg) : (g_tiles + 3) / 4 * a.n_wg * 8;
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: batch too large", who);
     a.g_tiles = (int)g_tiles;
@@ -452,7 +687,8 @@ int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint
 {
     if (!rowptr || !colidx || !rowmask) return fail(GGCN_EINVAL, "ggcn_csr_rowmask: null pointer");
     if (B <= 0 || T <= 0) return fail(GGCN_EINVAL, "ggcn_csr_rowmask: B=%d T=%d must be positive", B, T);
-    if (T > 32) return fail(GGCN_EUNSUPPORTED, "ggcn_csr_rowmask: T=%d > 32 (row masks are 32-bit)", T);
+    if (T > GGCN_MASK_MAX_T)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_csr_rowmask: T=%d > %d (row masks cover graphs of at most %d nodes)", T, GGCN_MASK_MAX_T, GGCN_MASK_MAX_T);
     const int64_t n = (int64_t)B * T;
     hipLaunchKernelGGL(rowmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rowptr, colidx, n, T,
                        rowmask);

@@ -69,7 +69,7 @@ def _block_operands(gc1, gc2, lib, st):
 def takes_block_path(x, csr, gc1, gc2):
     """True when the inference block runs as ONE launch: both layers on the one-launch layer path with the
     same arithmetic, and gc1's output width = gc2's (the reference's blocks are square, bert_amir5.py:559-560)."""
-    return (gc1.takes_fused_path(x, csr) and gc2.takes_fused_path(x, csr) and gc1.precision == gc2.precision
+    return (csr.T <= 32 and gc1.takes_fused_path(x, csr) and gc2.takes_fused_path(x, csr) and gc1.precision == gc2.precision
             and gc1.out_features == gc2.in_features and gc1.out_features == gc2.out_features)
 
 

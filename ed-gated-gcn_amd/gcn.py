@@ -141,7 +141,7 @@ class GraphConvolution(nn.Module):
         # what the reference's fp32 matmul accepts.  "f16mx8" (26 % faster) is opt-in: opt.ggcn_precision /
         # GGCN_PRECISION, for activations of ordinary magnitude (validate_range() checks a batch).
         self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "bf16x3")
-        # one-launch layer (fused_layer.hip) when the batch allows it: T <= 32, binary adjacency, bf16x3
+        # one-launch layer (fused_layer.hip) when the batch allows it: T <= 128, binary adjacency, split precision
         self.fused = bool(getattr(opt, "ggcn_fused", True)) and os.environ.get("GGCN_FUSED", "1") != "0"
         # dense adjacency handed to forward(): None = let the device detect edge weights (one 4-byte
         # read-back per conversion), True = promise 0/1 entries like the reference's (graph.py:66-74)
@@ -260,8 +260,8 @@ class GraphConvolution(nn.Module):
                                             or any(g is not None and g.requires_grad for g in gates))
 
     def takes_fused_path(self, text, csr):
-        """True when ``forward_gated`` will run as ONE launch (``ggcn_layer_fused``): graphs of <= 32
-        nodes, 0/1 adjacency, float32 features, a split-precision linear."""
+        """True when ``forward_gated`` will run as ONE launch (``ggcn_layer_fused``): graphs of <= 128
+        nodes (row masks), 0/1 adjacency, float32 features, a split-precision linear."""
         return (self.fused and self.precision in _capi.PACKED and csr.rowmask is not None and csr.is_binary
                 and text.dtype == torch.float32)
 

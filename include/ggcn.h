@@ -21,9 +21,9 @@
  *  - batched CSR: rowptr int32[N+1], colidx int32[nnz] holding GLOBAL node ids
  *    (block-diagonal: every id of row i lies in i's own graph), vals fp32[nnz]
  *    or NULL for a binary adjacency (all ones);
- *  - row masks (graphs of at most 32 nodes): rowmask uint32[N], bit j of word b*T+i set
- *    iff adj[b,i,j] != 0 -- the 0/1 adjacency at one bit per entry, consumed by
- *    ggcn_layer_fused.
+ *  - row masks (graphs of at most GGCN_MASK_MAX_T = 128 nodes): rowmask uint32[N][W], W = ceil(T/32) words
+ *    per node, bit j%32 of word j/32 of node b*T+i set iff adj[b,i,j] != 0 -- the 0/1 adjacency at one bit
+ *    per entry (T <= 32: one word per node), consumed by ggcn_layer_fused / ggcn_block_fused.
  */
 #ifndef GGCN_H
 #define GGCN_H
@@ -36,6 +36,7 @@ extern "C" {
 #endif
 
 #define GGCN_ABI_VERSION 5
+#define GGCN_MASK_MAX_T 128   /* largest graph the row-mask (one-launch) path takes */
 
 typedef void *ggcn_stream_t;
 
@@ -84,7 +85,7 @@ const char *ggcn_last_error(void);
  * (vals may be NULL when the caller knows adj is 0/1).  `capacity` is the
  * number of entries colidx/vals can hold (B*T*T always suffices); entries
  * beyond it are dropped (rowptr still holds the true counts).
- * rowmask (NULL or uint32[B*T], needs T <= 32) receives the row masks; flags (NULL or
+ * rowmask (NULL or uint32[B*T*ceil(T/32)], needs T <= GGCN_MASK_MAX_T) receives the row masks; flags (NULL or
  * one device int32) receives ggcn_csr_flags.
  * `workspace` needs ggcn_csr_workspace_bytes(B*T) bytes. */
 size_t ggcn_csr_workspace_bytes(int64_t n_rows);
@@ -94,7 +95,7 @@ int ggcn_csr_from_dense(const void *adj, int adj_dtype, int B, int T,
                         uint32_t *rowmask, int32_t *flags,
                         void *workspace, ggcn_stream_t stream);
 
-/* Row masks straight from the dense adjacency (T <= 32): one pass, no CSR arrays.  This is all
+/* Row masks straight from the dense adjacency (T <= GGCN_MASK_MAX_T): one pass, no CSR arrays.  This is all
  * ggcn_layer_fused needs, so the drop-in forward(text, adj) builds nothing else. */
 int ggcn_rowmask_from_dense(const void *adj, int adj_dtype, int B, int T,
                             int64_t stride_b, int64_t stride_r, int64_t stride_c,
@@ -107,7 +108,7 @@ int ggcn_csr_transpose(const int32_t *rowptr, const int32_t *colidx, const float
                        int32_t *rowptr_t, int32_t *colidx_t, float *vals_t, void *workspace,
                        ggcn_stream_t stream);
 
-/* Row masks from an existing batched CSR (T <= 32). */
+/* Row masks from an existing batched CSR (T <= GGCN_MASK_MAX_T). */
 int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
                      uint32_t *rowmask, ggcn_stream_t stream);
 

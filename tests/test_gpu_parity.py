@@ -102,7 +102,7 @@ def test_csr_weighted_and_large_t(pkg, dev):
     assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
     assert np.array_equal(csr.colidx[:nnz].cpu().numpy(), colidx)
     assert np.array_equal(csr.vals[:nnz].cpu().numpy(), vals)   # weights detected -> values kept
-    assert csr.rowmask is None                                   # T > 32
+    assert csr.rowmask is None                                   # T > 128: no row masks
 
 
 def test_csr_scan_across_many_tiles(pkg, dev):
@@ -1176,3 +1176,105 @@ def test_training_dropout_masks_the_gates_per_token(pkg, dev):
     assert m.gc1.weight.grad is not None and torch.isfinite(m.gc1.weight.grad).all()
     zero_frac = float((seen["x1"] == 0).float().mean())
     assert zero_frac < 0.02, "pooled features vanish with probability %.2f: the dropout mask is shared by the tokens" % zero_frac
+
+
+# ---------------------------------------------------------------- one launch per layer for 32 < T <= 128 (LitBank: ORI_ML = 100)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.uint8, torch.int64])
+@pytest.mark.parametrize("T", [33, 64, 65, 100, 128])
+def test_wide_row_masks_bit_exact(pkg, dev, T, dtype):
+    """ceil(T/32) mask words per node from the dense slice (one kernel), from a CSR (ggcn_csr_rowmask) and from
+    the host collation agree with numpy bit for bit."""
+    from ed_gated_gcn_amd import _capi, synth
+    B = 7
+    lens = np.random.default_rng(T).integers(1, T + 1, size=B)
+    adj = synth.dependency_batch(B, T, 4.0, seed=T, lengths=lens)
+    adj[:, 0, T - 1] = 1                                    # asymmetric, touches the last word
+    W = (T + 31) // 32
+    want = np.zeros((B * T, W), dtype=np.uint32)
+    rr, cc = np.nonzero(adj.reshape(B * T, T))
+    np.bitwise_or.at(want, (rr, cc // 32), (np.uint32(1) << (cc % 32).astype(np.uint32)))
+    big = torch.zeros(B, T + 9, T + 9, dtype=dtype, device=dev)
+    big[:, :T, :T] = torch.from_numpy(adj).to(dev).to(dtype)
+    csr = pkg.BatchedCSR.from_dense(big[:, :T, :T])
+    torch.cuda.synchronize()
+    assert csr.is_binary and np.array_equal(csr.rowmask.cpu().numpy().view(np.uint32).reshape(B * T, W), want)
+    rp, ci, _ = synth.csr_from_dense_host(adj)
+    host = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
+    assert torch.equal(host.rowmask, csr.rowmask)
+    lib = pkg.load_library()
+    m2 = torch.zeros(B * T * W, dtype=torch.int32, device=dev)
+    _capi.check(lib.ggcn_csr_rowmask(_capi.ptr(host.rowptr), _capi.ptr(host.colidx), B, T, _capi.ptr(m2),
+                                     _capi.stream_of(dev)), "ggcn_csr_rowmask")
+    assert torch.equal(m2, csr.rowmask)
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rp)     # the CSR arrays behind the masks are the same graph
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
+@pytest.mark.parametrize("B,T,K,F,padded", [(5, 100, 256, 256, True), (9, 64, 768, 768, False), (3, 33, 72, 40, True),
+                                            (4, 128, 300, 300, False), (6, 96, 64, 512, True), (2, 65, 9, 13, True),
+                                            (17, 48, 128, 128, True)])
+def test_wide_graph_layer_one_launch_vs_oracle(pkg, dev, precision, B, T, K, F, padded):
+    """ggcn_layer_fused on graphs of 33..128 nodes (64- / 128-row slots, SB x SB adjacency blocks) against the
+    oracle (gcn.py:30-45 + both gates and pools), against the unfused path, and through a host-collated CSR."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(B * T + F)
+    lens = rng.integers(max(1, T // 4), T + 1, size=B) if padded else None
+    adj = synth.dependency_batch(B, T, 4.0, seed=B + T, lengths=lens)
+    x = rng.standard_normal((B, T, K)).astype(np.float32)
+    w, b = synth.layer_params(K, F, seed=4)
+    g1 = rng.uniform(-1.0, 1.0, (B, F)).astype(np.float32)            # negative gates: the min side of the pools
+    g2 = rng.uniform(0.1, 0.9, (B, F)).astype(np.float32)
+    t = torch.from_numpy
+    y = ref_dense.graph_convolution(t(x), t(adj.astype(np.float32)), t(w), t(b))
+    want = {"out": y * t(g2)[:, None, :], "pa": torch.max(y * t(g1)[:, None, :], 1)[0], "pb": torch.max(y * t(g2)[:, None, :], 1)[0]}
+    fused, unfused = _layer(pkg, dev, w, b, precision, True), _layer(pkg, dev, w, b, precision, False)
+    xd, ad, g1d, g2d = t(x).to(dev), t(adj).to(dev), t(g1).to(dev), t(g2).to(dev)
+    csr = pkg.BatchedCSR.from_dense(ad)
+    assert fused.takes_fused_path(xd, csr)
+    kw = dict(store_gate=g2d, pool_gate_a=g1d, pool_gate_b=g2d, want_pool_a=True, want_pool_b=True)
+    with torch.no_grad():
+        got = fused.forward_gated(xd, ad, **kw)
+        ref2 = unfused.forward_gated(xd, ad, **kw)
+        rp, ci, _ = synth.csr_from_dense_host(adj)
+        via_host = fused.forward_gated(xd, pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev), **kw)
+        pools_only = fused.forward_gated(xd, ad, pool_gate_a=g1d, pool_gate_b=g2d, want_out=False, want_pool_a=True, want_pool_b=True)
+    tol = TOL[precision]
+    for name, gv, uv, hv in zip(("out", "pa", "pb"), got, ref2, via_host):
+        np.testing.assert_allclose(gv.cpu().numpy(), want[name].numpy(), rtol=0, atol=tol, err_msg=name)
+        assert float((gv - uv).abs().max()) <= tol, name
+        assert torch.equal(gv, hv), name
+    assert pools_only[0] is None and torch.equal(pools_only[1], got[1]) and torch.equal(pools_only[2], got[2])
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
+def test_wide_graph_block_litbank_shape(pkg, dev, precision):
+    """The gated block at LitBank's shape (constant.py:227: ORI_ML = 100; hidden 256): two one-launch layers,
+    xy folded into them, against the oracle block; training through the same path gives the oracle's gradients."""
+    from ed_gated_gcn_amd import synth
+    B, T, H = 12, 100, 256
+    rng = np.random.default_rng(7)
+    adj = synth.dependency_batch(B, T, 3.5, seed=3, lengths=rng.integers(10, T + 1, size=B))
+    x = rng.standard_normal((B, T, H)).astype(np.float32)
+    g1 = (1 / (1 + np.exp(-rng.standard_normal((B, H))))).astype(np.float32)
+    g2 = (1 / (1 + np.exp(-rng.standard_normal((B, H))))).astype(np.float32)
+    (w1, b1), (w2, b2) = synth.layer_params(H, H, seed=1), synth.layer_params(H, H, seed=2)
+    ref = _oracle_block(x, adj.astype(np.float32), g1, g2, w1, b1, w2, b2)
+    gc1, gc2 = _layer(pkg, dev, w1, b1, precision), _layer(pkg, dev, w2, b2, precision)
+    td = lambda a: torch.from_numpy(a).to(dev)
+    with torch.no_grad():
+        r = pkg.gated_gcn_block(td(x), td(adj), td(g1), td(g2), gc1, gc2, want_gcn1=True)
+    for k in ("gcn1", "x1", "y1", "x", "out"):
+        np.testing.assert_allclose(r[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=TOL[precision], err_msg=k)
+    assert abs(float(r["xy"]) - float(ref["xy"])) <= 1e-4 * max(1.0, abs(float(ref["xy"])))
+    xg = td(x).requires_grad_()
+    gc1.train(); gc2.train()
+    rt = pkg.gated_gcn_block(xg, td(adj), td(g1), td(g2), gc1, gc2)
+    (rt["x"] * rt["x"]).sum().backward()                  # no arg-max in the loss: near-ties cannot re-route the gradient
+    xr = torch.from_numpy(x).requires_grad_()
+    w1r, b1r = torch.from_numpy(w1).requires_grad_(), torch.from_numpy(b1).requires_grad_()
+    rr = ref_dense.gated_block(xr, torch.from_numpy(adj.astype(np.float32)), torch.from_numpy(g1), torch.from_numpy(g2),
+                               w1r, b1r, torch.from_numpy(w2), torch.from_numpy(b2))
+    (rr["x"] * rr["x"]).sum().backward()
+    _grad_close(xg.grad, xr.grad, "x", rel=5e-4)
+    _grad_close(gc1.weight.grad, w1r.grad, "w1", rel=5e-4)
+    _grad_close(gc1.bias.grad, b1r.grad, "b1", rel=5e-4)
