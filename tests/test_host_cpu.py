@@ -129,7 +129,12 @@ def test_from_arrays_validates():
     assert ok.vals is None
     big = synth.dependency_batch(1, 40, 3.0)
     rp, ci, _ = synth.csr_from_dense_host(big)
-    assert BatchedCSR.from_arrays(rp, ci, 1, 40, "cpu").rowmask is None   # T > 32: no masks
+    wide = BatchedCSR.from_arrays(rp, ci, 1, 40, "cpu").rowmask.numpy().view(np.uint32).reshape(40, 2)   # 2 words per node
+    bits = ((wide[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(40, 64)[:, :40]
+    assert np.array_equal(bits, (big[0] != 0).astype(np.uint32))
+    huge = synth.dependency_batch(1, 130, 3.0)
+    rp, ci, _ = synth.csr_from_dense_host(huge)
+    assert BatchedCSR.from_arrays(rp, ci, 1, 130, "cpu").rowmask is None   # T > 128: no masks
 
 
 def test_graph_batcher_matches_dense_slice():
