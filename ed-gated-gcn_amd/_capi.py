@@ -56,8 +56,8 @@ PROTOTYPES = {
 }
 
 ABI_VERSION = 5
-PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2}
-PACKED = ("bf16x3", "f16mx8")  # precisions whose linear reads a ggcn_weight_pack image
+PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2, "f16": 3}
+PACKED = ("bf16x3", "f16mx8", "f16")  # precisions whose linear reads a ggcn_weight_pack image ("f16": half features only)
 FLAG_WEIGHTED = 1
 
 

@@ -139,8 +139,8 @@ int ggcn_aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const in
 int ggcn_linear_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M, int K, int F,
                   int precision, ggcn_stream_t stream)
 {
-    if (precision != GGCN_PREC_BF16X3 && precision != GGCN_PREC_F16MX8)
-        return fail(GGCN_EUNSUPPORTED, "ggcn_linear_h: precision %d (use bf16x3 or f16mx8)", precision);
+    if (precision != GGCN_PREC_BF16X3 && precision != GGCN_PREC_F16MX8 && precision != GGCN_PREC_F16)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_linear_h: precision %d (use bf16x3, f16mx8 or f16)", precision);
     if (!X || !Y) return fail(GGCN_EINVAL, "ggcn_linear_h: null pointer");
     if (M <= 0 || K <= 0 || F <= 0)
         return fail(GGCN_EINVAL, "ggcn_linear_h: M=%lld K=%d F=%d must be positive", (long long)M, K, F);

@@ -14,7 +14,7 @@
 // Kernel shape, operand lane maps and the measured scheduling notes: bf16x3_core.h (the main
 // loop is shared with fused_layer.hip).  This file adds the weight packers of both schemes and the
 // store epilogue (16-byte row stores through LDS for aligned fp32 output).
-#include "f16mx8_core.h"
+#include "f16_core.h"
 
 namespace ggcn {
 namespace {
@@ -219,6 +219,71 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_split_kernel(
     }
 }
 
+// fp16 features x fp16 image of W (f16_core.h): Y[M,F] (fp16) = X[M,K] (fp16) . W, fp32 accumulation
+template <bool AVEC, bool KFULL>
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_f16_kernel(
+    const __half *__restrict__ X, int64_t ldx, const char *__restrict__ wpack, __half *__restrict__ Y, int64_t ldy,
+    int64_t M, int K, int F, int m_tiles, int n_wg, int records)
+{
+    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+    int m_tile, n_wgi;
+    if (!tile_of_block(blockIdx.x, m_tiles, n_wg, m_tile, n_wgi)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN;
+    const int64_t m0 = (int64_t)m_tile * BM;
+    const int n_tiles_total = (F + NT - 1) / NT;
+    const int nt0 = n_wgi * (BN / NT) + wn * RN;
+    const __half *arow[f16::NP16];
+    bool avalid[f16::NP16];
+#pragma unroll
+    for (int i = 0; i < f16::NP16; ++i) {
+        int64_t gm = m0 + 32 * i + (tid >> 3);
+        gm = gm < M ? gm : M - 1;     // a row of A only feeds the same row of Y, never stored
+        arow[i] = X + gm * ldx;
+        avalid[i] = true;
+    }
+    f32x16 acc[4][RN];
+    f16::mainloop<AVEC, KFULL, false>(arow, avalid, wpack, K, records, 0, nt0, n_tiles_total, lds, acc);
+    // fp16 output: two rows x 32 columns of a tile per store instruction (64-byte row segments)
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int gn = (nt0 + j) * NT + (lane & 31);
+        if (gn >= F) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t gmb = m0 + i * 32 + 4 * (lane >> 5);
+            __half *yb = Y + gmb * ldy + gn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (gmb + (r & 3) + 8 * (r >> 2) < M)
+                    yb[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = __float2half_rn(acc[i][j][r]);
+        }
+    }
+}
+
+int launch_linear_f16(const __half *X, int64_t ldx, const void *wpack, __half *Y, int64_t ldy, int64_t M, int K, int F,
+                      hipStream_t st)
+{
+    if (!wpack) return fail(GGCN_EINVAL, "ggcn_linear_h(f16): wpack is NULL (ggcn_weight_pack with GGCN_PREC_F16MX8)");
+    if (!aligned16(wpack)) return fail(GGCN_EINVAL, "ggcn_linear_h(f16): wpack must be 16-byte aligned");
+    const bool avec = (K % 8 == 0) && (ldx % 8 == 0) && aligned16(X);
+    const bool kfull = (K % f16::BK2 == 0);
+    const int records = round_up(K, BK) / BK;
+    const int64_t m_tiles = (M + BM - 1) / BM;
+    const int n_wg = (F + BN - 1) / BN;
+    const int64_t grid = grid_for(m_tiles, n_wg);
+    if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_linear_h(f16): M too large");
+    const char *wp = static_cast<const char *>(wpack);
+#define GGCN_LAUNCH(AV, KF)                                                                                           \
+    hipLaunchKernelGGL((linear_f16_kernel<AV, KF>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, wp, Y, ldy, M, K, \
+                       F, (int)m_tiles, n_wg, records)
+    if (avec && kfull) GGCN_LAUNCH(true, true);
+    else if (avec) GGCN_LAUNCH(true, false);
+    else GGCN_LAUNCH(false, false);
+#undef GGCN_LAUNCH
+    return check_launch("ggcn_linear_h(f16)");
+}
+
 template <int SCH, typename ET>
 int launch_linear(const ET *X, int64_t ldx, const void *wpack, ET *Y, int64_t ldy, int64_t M, int K, int F,
                   hipStream_t st)
@@ -253,7 +318,7 @@ size_t weight_pack_bytes(int K, int F, int precision)
     if (K <= 0 || F <= 0) return 0;
     const size_t stages = (size_t)bx3::round_up(K, bx3::BK) / bx3::BK;  // whole 32-deep stages
     const size_t n_tiles = (size_t)bx3::round_up(F, bx3::NT) / bx3::NT;
-    if (precision == GGCN_PREC_F16MX8) return n_tiles * stages * mx8::STAGE_PACK_BYTES;
+    if (precision == GGCN_PREC_F16MX8 || precision == GGCN_PREC_F16) return n_tiles * stages * mx8::STAGE_PACK_BYTES;
     return n_tiles * stages * 2 * 2 * bx3::FRAG_BYTES;
 }
 
@@ -266,7 +331,7 @@ int weight_pack(const float *W, int64_t ldw, int K, int F, int precision, bool t
     const int k_steps = round_up(K, BK) / KSTEP;
     const int n_tiles = round_up(F, NT) / NT;
     if (k_steps > 65535) return fail(GGCN_EUNSUPPORTED, "ggcn_weight_pack: K too large");
-    if (precision == GGCN_PREC_F16MX8) {
+    if (precision == GGCN_PREC_F16MX8 || precision == GGCN_PREC_F16) {   // GGCN_PREC_F16 reads the fp16 part of the same image
         const dim3 grid((unsigned)n_tiles, (unsigned)(k_steps / 2));
         if (transposed)
             hipLaunchKernelGGL(weight_pack_mx8_kernel<true>, grid, dim3(64), 0, st, W, ldw, K, F, k_steps / 2,
@@ -313,6 +378,7 @@ int linear_packed_h(const void *X, int64_t ldx, const void *wpack, void *Y, int6
 {
     const __half *x = static_cast<const __half *>(X);
     __half *y = static_cast<__half *>(Y);
+    if (precision == GGCN_PREC_F16) return launch_linear_f16(x, ldx, wpack, y, ldy, M, K, F, st);
     if (precision == GGCN_PREC_F16MX8) return launch_linear<1, __half>(x, ldx, wpack, y, ldy, M, K, F, st);
     return launch_linear<0, __half>(x, ldx, wpack, y, ldy, M, K, F, st);
 }

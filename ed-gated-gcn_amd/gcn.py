@@ -195,6 +195,9 @@ class GraphConvolution(nn.Module):
         # float16 features (BASELINE configs[3]) are an extension: the reference itself raises a
         # dtype mismatch for half inputs.  Weights, bias, gates stay float32.
         _require_gpu_f32("text", text, allow_half=True)
+        if self.precision == "f16" and text.dtype != torch.float16:
+            raise RuntimeError("precision='f16' (plain fp16 MFMA) is for float16 features only; float32 features take "
+                               "'bf16x3', 'f16mx8' or 'fp32'")
         if text.dtype == torch.float16 and self.precision not in _capi.PACKED:
             raise RuntimeError("float16 features need precision='bf16x3' or 'f16mx8' (the exact-fp32 linear is "
                                "fp32 only)")
@@ -203,7 +206,8 @@ class GraphConvolution(nn.Module):
         if self.weight.device != text.device:
             raise RuntimeError("weight is on %s but text is on %s" % (self.weight.device, text.device))
         if self.precision not in _capi.PREC:
-            raise RuntimeError("unknown precision %r (use 'bf16x3', 'f16mx8' or 'fp32')" % (self.precision,))
+            raise RuntimeError("unknown precision %r (use 'bf16x3', 'f16mx8', 'fp32', or 'f16' for float16 features)"
+                               % (self.precision,))
 
     def validate_range(self, text=None):
         """On-demand range check for ``precision='f16mx8'`` (one pass over the data, one read-back: NOT part of

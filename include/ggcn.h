@@ -68,10 +68,13 @@ enum ggcn_precision {
     GGCN_PREC_BF16X3 = 0,  /* fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per
                               product, fp32 accumulate: |err| ~ 2^-16 |x||w| per product */
     GGCN_PREC_FP32 = 1,    /* v_mfma_f32_32x32x2_f32: a k-ordered fp32 FMA chain, exact fp32 */
-    GGCN_PREC_F16MX8 = 2   /* operands split into fp16 hi + residual; hi.hi on the fp16 MFMA, both cross
+    GGCN_PREC_F16MX8 = 2,  /* operands split into fp16 hi + residual; hi.hi on the fp16 MFMA, both cross
                               terms in ONE block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4):
                               2/3 of bf16x3's matrix-core time, |err| ~ 2^-15 |x||w| per product.
                               Needs |x|, |w| < 65504 (fp16 range; larger values saturate to inf) */
+    GGCN_PREC_F16 = 3      /* HALF-PRECISION FEATURES ONLY (ggcn_linear_h): plain fp16 MFMA on the fp16 image of W
+                              (the fp16 fragments of the GGCN_PREC_F16MX8 pack), fp32 accumulate; |err| ~ 2^-12 |x||w|
+                              per product -- below the rounding of the fp16 output it feeds */
 };
 
 int ggcn_abi_version(void);

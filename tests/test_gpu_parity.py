@@ -1278,3 +1278,54 @@ def test_wide_graph_block_litbank_shape(pkg, dev, precision):
     _grad_close(xg.grad, xr.grad, "x", rel=5e-4)
     _grad_close(gc1.weight.grad, w1r.grad, "w1", rel=5e-4)
     _grad_close(gc1.bias.grad, b1r.grad, "b1", rel=5e-4)
+
+
+# ---------------------------------------------------------------- fp16 features: the plain fp16 MFMA linear (config 4)
+@pytest.mark.parametrize("M,K,F", [(512, 1024, 1024), (300, 96, 200), (33, 72, 13), (1000, 64, 512), (7, 9, 5)])
+def test_f16_linear_for_half_features(pkg, dev, M, K, F):
+    """precision='f16' (half features only): X exact, W rounded to fp16, fp32 accumulation, fp16 output -- against
+    float64 on the fp16-rounded inputs with the fp16-rounded weights (tight) and with the fp32 weights (config 4's
+    gate, SURVEY 8d: atol 2e-3); float32 features are refused."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(M + K)
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).half()
+    w, b = synth.layer_params(K, F, seed=2)
+    m = _layer(pkg, dev, w, b, "f16")
+    with torch.no_grad():
+        y = m.linear(x.to(dev))
+    assert y.dtype == torch.float16
+    w16 = torch.from_numpy(w).half().double()
+    ref_tight = x.double() @ w16
+    ref_gate = x.double() @ torch.from_numpy(w).double()
+    scale = max(1.0, float(ref_gate.abs().max()))
+    assert float((y.cpu().double() - ref_tight).abs().max()) <= 6e-4 * scale        # fp16 output rounding (2^-11) + fp32 sums
+    assert float((y.cpu().double() - ref_gate).abs().max()) <= 2e-3 * scale
+    with pytest.raises(RuntimeError, match="float16 features only"):
+        m(torch.randn(2, 3, K, device=dev), torch.eye(3, device=dev).expand(2, -1, -1))
+
+
+def test_f16_precision_layer_config4_sample(pkg, dev):
+    """BASELINE configs[3] in small with precision='f16': 4 graphs x 512 tokens, hidden 1024, fp16 features; the gated
+    layer against the fp32 reference on the fp16-rounded inputs (atol 2e-3) and against precision='f16mx8'."""
+    from ed_gated_gcn_amd import synth
+    B, T, H = 4, 512, 1024
+    rng = np.random.default_rng(9)
+    adj = synth.dependency_batch(B, T, 6.0, seed=1)
+    x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32)).half()
+    w, b = synth.layer_params(H, H, seed=1)
+    g1 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32)))
+    t = torch.from_numpy
+    y = ref_dense.graph_convolution(x.float(), t(adj.astype(np.float32)), t(w), t(b))
+    want_pa = torch.max(y * g1[:, None, :], 1)[0]
+    rp, ci, _ = synth.csr_from_dense_host(adj)
+    csr = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
+    outs = {}
+    for prec in ("f16", "f16mx8"):
+        m = _layer(pkg, dev, w, b, prec)
+        with torch.no_grad():
+            out, pa, _ = m.forward_gated(x.to(dev), csr, pool_gate_a=g1.to(dev), want_pool_a=True)
+        assert out.dtype == torch.float16
+        np.testing.assert_allclose(out.float().cpu().numpy(), y.numpy(), rtol=0, atol=2e-3)
+        np.testing.assert_allclose(pa.cpu().numpy(), want_pa.numpy(), rtol=0, atol=2e-3)
+        outs[prec] = out
+    assert float((outs["f16"].float() - outs["f16mx8"].float()).abs().max()) <= 2e-3
