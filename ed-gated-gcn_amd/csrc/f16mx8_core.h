@@ -96,6 +96,16 @@ __device__ __forceinline__ Split4 split4(float x0, float x1, float x2, float x3)
 // costs the correction its accuracy and |x| > 65504 saturates like any fp16 pipeline.
 __device__ __forceinline__ void set_cvt_saturate(bool on) { __builtin_amdgcn_s_setreg(1 | (23 << 6), on ? 1 : 0); }
 
+// Chunk address in the fp8 plane: the A planes' swizzle (a_lds_off) XOR 2 on rows 2, 3 (mod 4).  The plane is written
+// one dword per lane (ds_write_b32: 32 lanes = 4 rows x 8 dwords); with the plain swizzle rows r and r + 2 put their 8
+// dwords on the same 32 banks (2-way: SQ_LDS_BANK_CONFLICT 12 % of the LDS cycles); with the extra bit rows r, r + 1 take
+// the two xl chunks' banks and rows r + 2, r + 3 the other two.  Rows with equal row & 3 get the same extra bit, so the
+// 16-byte fragment reads stay conflict-free.
+__device__ __forceinline__ int q_lds_off(int row, int chunk)
+{
+    return row * ROWB + ((chunk ^ ((row >> 2) & 3) ^ (((row >> 1) & 1) << 1)) << 4);
+}
+
 #define GGCN_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <typename AT, bool AVEC, bool KFULL, bool ZROWS>
@@ -158,8 +168,8 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             // q plane: 16-byte chunk hh = the four xl8 dwords lane half hh reads (k = 8hh..8hh+7, 16+8hh..16+8hh+7),
             // chunk 2+hh = its four xh8 dwords -- the MX operand's two scale blocks are two plain 16-byte reads
             const int g = kq >> 2, hh = (g >> 1) & 1, pos = (g & 1) + 2 * (g >> 2);
-            *reinterpret_cast<uint32_t *>(q_plane + a_lds_off(row, hh) + 4 * pos) = (uint32_t)sp[q].l8;
-            *reinterpret_cast<uint32_t *>(q_plane + a_lds_off(row, 2 + hh) + 4 * pos) = (uint32_t)sp[q].h8;
+            *reinterpret_cast<uint32_t *>(q_plane + q_lds_off(row, hh) + 4 * pos) = (uint32_t)sp[q].l8;
+            *reinterpret_cast<uint32_t *>(q_plane + q_lds_off(row, 2 + hh) + 4 * pos) = (uint32_t)sp[q].h8;
         }
     };
 
@@ -223,8 +233,8 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         // The dwords arrive in operand order: no register shuffle sits between the reads and the MFMA, so the
         // reads' latency hides behind the MFMAs issued before their first use.  (The earlier {xl8,xh8} pair
         // layout needed 8 moves per operand right behind the reads: an exposed LDS round trip four times a stage.)
-        const i32x4 lo = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, f_half));
-        const i32x4 hi = *reinterpret_cast<const i32x4 *>(q_plane + a_lds_off(row, 2 + f_half));
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(q_plane + q_lds_off(row, f_half));
+        const i32x4 hi = *reinterpret_cast<const i32x4 *>(q_plane + q_lds_off(row, 2 + f_half));
         a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
