@@ -348,8 +348,22 @@ bool side_aligned(const float *bias, const float *sg, const float *ga, const flo
 // the chunked direct form above stays faster (317 vs 344 us), so fp32 keeps it.
 constexpr int kNarrowMaxT = 768;  // 96 KiB of slab
 constexpr int kIdxCap = 4096;     // edges per graph whose column ids are staged (8 KiB as uint16)
-template <typename E, bool HAS_VALS, bool NORM>
-__global__ __launch_bounds__(256) void aggregate_narrow(
+// acc[0..7] += w * (the 8 halves of v): v_fma_mix_f32 reads the fp16 operand straight from its half of the dword
+// (fp32 accumulate, no separate conversion: 8 VALU per 16 bytes instead of 16)
+__device__ __forceinline__ void fma_half8(const uint4 &v, float w, float (&acc)[8])
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * q]) : "v"(d[q]), "v"(w));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * q + 1]) : "v"(d[q]), "v"(w));
+    }
+}
+
+// NW: wavefronts per workgroup (4, or 8 for T >= 256: the slab's LDS is the same, so twice the wavefronts share a CU's
+// two resident workgroups -- the row loop is a chain of dependent LDS reads and lives on wavefront count)
+template <typename E, bool HAS_VALS, bool NORM, int NW, int MAXQ>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void aggregate_narrow(   // two workgroups per CU either way
     const E *__restrict__ Hd, int64_t ldh, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ colidx, const float *__restrict__ vals, const float *__restrict__ src_scale,
     const float *__restrict__ bias, int n_graphs, int T, int F, int n_slabs,
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(256) void aggregate_narrow(
 {
     constexpr int EPL = 16 / (int)sizeof(E);  // elements per lane: 4 fp32 / 8 fp16
     constexpr int kCols = 8 * EPL;            // columns per slab (128 bytes)
-    __shared__ float red[2][kWaves][kCols];
+    __shared__ float red[2][NW][kCols];
     __shared__ int s_rp[kNarrowMaxT + 1];        // row pointers relative to the graph's first edge
     __shared__ unsigned short s_col[kIdxCap];    // column ids relative to the graph's first node
     extern __shared__ __attribute__((aligned(16))) char tile_raw[];  // [T][128 B]
@@ -393,23 +407,24 @@ __global__ __launch_bounds__(256) void aggregate_narrow(
     // ---- the slab's rows leave for LDS first (up to 24 x 16 B per thread in flight), the graph's CSR
     // is fetched and staged while they travel ----
     const int r_first = wave * 8 + grp;
-    constexpr int kMaxSteps = kNarrowMaxT / 32;
+    constexpr int kRowsPerStep = 8 * NW;
+    constexpr int kMaxSteps = MAXQ;   // ceil(T / kRowsPerStep) <= MAXQ (the launcher picks): 16-byte loads in flight per thread
     uint4 st4[kMaxSteps];
 #pragma unroll
     for (int q = 0; q < kMaxSteps; ++q) {
-        const int r = r_first + 32 * q;
+        const int r = r_first + kRowsPerStep * q;
         st4[q] = make_uint4(0u, 0u, 0u, 0u);
         if (r < T && live) st4[q] = *reinterpret_cast<const uint4 *>(Hd + (node0 + r) * ldh + col);
     }
     const int e_base = rowptr[node0];
     const int nnz_g = rowptr[node0 + T] - e_base;
     const bool staged = nnz_g <= kIdxCap;  // workgroup-uniform
-    for (int i = threadIdx.x; i <= T; i += 256) s_rp[i] = rowptr[node0 + i] - e_base;
+    for (int i = threadIdx.x; i <= T; i += 64 * NW) s_rp[i] = rowptr[node0 + i] - e_base;
     if (staged)
-        for (int j = threadIdx.x; j < nnz_g; j += 256) s_col[j] = (unsigned short)(colidx[e_base + j] - (int)node0);
+        for (int j = threadIdx.x; j < nnz_g; j += 64 * NW) s_col[j] = (unsigned short)(colidx[e_base + j] - (int)node0);
 #pragma unroll
     for (int q = 0; q < kMaxSteps; ++q) {
-        const int r = r_first + 32 * q;
+        const int r = r_first + kRowsPerStep * q;
         if (r < T) *reinterpret_cast<uint4 *>(tile_raw + (size_t)r * 128 + piece * 16) = st4[q];
     }
     __syncthreads();
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(256) void aggregate_narrow(
     const int32_t *cg = colidx + e_base;
     const float *vg = HAS_VALS ? vals + e_base : nullptr;
     auto col_of = [&](int e) -> int { return staged ? (int)s_col[e] : cg[e] - (int)node0; };  // local source row
-    for (int r = r_first; r < T; r += 32) {   // rows differ per lane group: plain divergent control flow
+    for (int r = r_first; r < T; r += kRowsPerStep) {   // rows differ per lane group: plain divergent control flow
         const int64_t node = node0 + r;
         int e = s_rp[r];
         const int end = s_rp[r + 1];
@@ -431,6 +446,14 @@ __global__ __launch_bounds__(256) void aggregate_narrow(
             float w0 = 1.0f, w1 = 1.0f;
             if constexpr (HAS_VALS) { w0 = vg[e]; w1 = vg[e + 1]; }
             if constexpr (!NORM) { w0 *= src_scale[node0 + c0]; w1 *= src_scale[node0 + c1]; }
+            if constexpr (std::is_same<E, __half>::value) {   // fp16 slab: fused convert-and-add
+                const uint4 r0 = *reinterpret_cast<const uint4 *>(tile + (size_t)c0 * kCols + piece * EPL);
+                const uint4 r1 = *reinterpret_cast<const uint4 *>(tile + (size_t)c1 * kCols + piece * EPL);
+                fma_half8(r0, w0, acc);
+                fma_half8(r1, w1, acc);
+                if constexpr (HAS_VALS || !NORM) { wsum += w0; wsum += w1; }
+                continue;
+            }
             float h0[EPL], h1[EPL];
             Seg<E, EPL>::load(tile + (size_t)c0 * kCols + piece * EPL, h0);
             Seg<E, EPL>::load(tile + (size_t)c1 * kCols + piece * EPL, h1);
@@ -449,15 +472,21 @@ __global__ __launch_bounds__(256) void aggregate_narrow(
             float w0 = 1.0f;
             if constexpr (HAS_VALS) w0 = vg[e];
             if constexpr (!NORM) w0 *= src_scale[node0 + c0];
-            float h0[EPL];
-            Seg<E, EPL>::load(tile + (size_t)c0 * kCols + piece * EPL, h0);
-            if constexpr (HAS_VALS || !NORM) {
-#pragma unroll
-                for (int k = 0; k < EPL; ++k) acc[k] = fmaf(w0, h0[k], acc[k]);
-                wsum += w0;
+            if constexpr (std::is_same<E, __half>::value) {
+                const uint4 r0 = *reinterpret_cast<const uint4 *>(tile + (size_t)c0 * kCols + piece * EPL);
+                fma_half8(r0, w0, acc);
+                if constexpr (HAS_VALS || !NORM) wsum += w0;
             } else {
+                float h0[EPL];
+                Seg<E, EPL>::load(tile + (size_t)c0 * kCols + piece * EPL, h0);
+                if constexpr (HAS_VALS || !NORM) {
 #pragma unroll
-                for (int k = 0; k < EPL; ++k) acc[k] += h0[k];
+                    for (int k = 0; k < EPL; ++k) acc[k] = fmaf(w0, h0[k], acc[k]);
+                    wsum += w0;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < EPL; ++k) acc[k] += h0[k];
+                }
             }
         }
         const float inv = NORM ? 1.0f / ((HAS_VALS ? wsum : (float)cnt) + 1.0f) : 1.0f;  // gcn.py:35
@@ -497,7 +526,7 @@ __global__ __launch_bounds__(256) void aggregate_narrow(
             if (tcol < F) {
                 float ma = red[0][0][threadIdx.x], mb = red[1][0][threadIdx.x];
 #pragma unroll
-                for (int w = 1; w < kWaves; ++w) {
+                for (int w = 1; w < NW; ++w) {
                     ma = fmaxf(ma, red[0][w][threadIdx.x]);
                     mb = fmaxf(mb, red[1][w][threadIdx.x]);
                 }
@@ -522,18 +551,27 @@ bool launch_narrow(const E *Hd, int64_t ldh, const int32_t *rowptr, const int32_
     const int64_t blocks = ((int64_t)B + 7) / 8 * 8 * n_slabs;
     if (blocks > (int64_t)INT32_MAX) return false;
     const size_t lds = (size_t)T * 128;
+    const int nw = T >= 256 ? 8 : 4;
     auto go = [&](auto kern) {
-        static bool raised = false;  // dynamic LDS above the default 64 KiB limit needs the attribute once
-        if (!raised) {
+        // dynamic LDS above the default 64 KiB limit needs the attribute (cheap; set on every launch: one static flag
+        // per lambda would be shared by the instantiations)
+        {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kNarrowMaxT * 128);
-            raised = true;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, Hd, ldh, rowptr, colidx, vals, src_scale, bias,
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * nw), lds, st, Hd, ldh, rowptr, colidx, vals, src_scale, bias,
                            B, T, F, n_slabs, sg, ga, gb, out, ldo, pa, pb);
     };
-    if (vals) go(aggregate_narrow<E, true, NORM>);
-    else go(aggregate_narrow<E, false, NORM>);
+    if (nw == 8 && T > 512) {          // 513..768 rows: 12 steps of 64 rows
+        if (vals) go(aggregate_narrow<E, true, NORM, 8, 12>);
+        else go(aggregate_narrow<E, false, NORM, 8, 12>);
+    } else if (nw == 8) {              // 256..512 rows: 8 steps of 64 rows
+        if (vals) go(aggregate_narrow<E, true, NORM, 8, 8>);
+        else go(aggregate_narrow<E, false, NORM, 8, 8>);
+    } else {                           // < 256 rows: 8 steps of 32 rows
+        if (vals) go(aggregate_narrow<E, true, NORM, 4, 8>);
+        else go(aggregate_narrow<E, false, NORM, 4, 8>);
+    }
     rc = check_launch(NORM ? "ggcn_aggregate" : "ggcn_aggregate_t");
     return true;
 }
