@@ -277,6 +277,10 @@ def main():
 
     def step():
         with torch.no_grad():
+            # step i-2's gather read the output buffer this step's replay is about to overwrite (graph copy i % 2) and
+            # holds the gather slot this step will reuse: finish it FIRST (it was launched two steps ago)
+            while len(pending) > 1:
+                gather.finish(pending.pop(0))
             if graphs is None:
                 r = forward()
             else:
@@ -284,8 +288,6 @@ def main():
                 g.replay()
             counter[0] += 1
             if world > 1:
-                while len(pending) > 1:
-                    gather.finish(pending.pop(0))     # step i-2's gather (its buffers are about to be reused)
                 pending.append(gather.start(r["out"]))
         return r
 
