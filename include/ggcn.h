@@ -207,13 +207,15 @@ int ggcn_aggregate_h(const void *Hd, int64_t ldh,
                      void *out, int64_t ldo, float *pool_a, float *pool_b,
                      ggcn_stream_t stream);
 
-/* ---- one whole gated layer in one launch (graphs of <= 32 nodes, binary adjacency) ----
+/* ---- one whole gated layer in one launch (graphs of <= GGCN_MASK_MAX_T = 128 nodes, binary adjacency) ----
  * Replaces models/gcn.py:34-45 + models/bert_amir5.py:627-640 without materialising
  * `hidden`: the linear's accumulator tile (one graph x 32 features) is multiplied by
  * the graph's 0/1 adjacency with a second MFMA, then divided, biased, gated, pooled and
  * stored.  Same outputs and argument meaning as ggcn_linear(GGCN_PREC_BF16X3) followed by
  * ggcn_aggregate; X is [B*T, K], wpack from ggcn_weight_pack(K, F, precision), rowmask
- * uint32[B*T]; precision is GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8.
+ * uint32[B*T][ceil(T/32)]; precision is GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8.  T <= 32: one 32x32
+ * accumulator tile is one graph.  32 < T <= 128: a graph takes a 64- or 128-row slot of a wavefront's tile and
+ * its adjacency is applied as ceil(T/32)^2 blocks of 32x32 bits (LitBank: ORI_ML = 100, constant.py:227).
  * The gate-diversity regulariser (models/bert_amir5.py:638) can ride along instead of taking
  * ggcn_gate_overlap's two launches: overlap_partial (NULL or float[B * ceil(F/64)]) receives, per graph
  * and 64-column group, sum_f pool_a[g,f]*pool_b[g,f] of THIS launch (layer 1: x1.y1); overlap_in /
