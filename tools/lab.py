@@ -86,6 +86,14 @@ def time_variants(what, names):
         lib, pack, prec = libs[n]
         if what == "linear":
             rc = lib.ggcn_linear(p(x), H, p(w), H, p(pack), p(y), H, N, H, H, prec, st)
+        elif what == "linear_pp":     # lab_pp.hip: ping-pong form of the f16mx8 linear (falls back to the plain linear)
+            if hasattr(lib, "ggcn_lab_linear_pp"):
+                lib.ggcn_lab_linear_pp.restype = ctypes.c_int
+                lib.ggcn_lab_linear_pp.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                   ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+                rc = lib.ggcn_lab_linear_pp(p(x), H, p(pack), p(y), H, N, H, H, st)
+            else:
+                rc = lib.ggcn_linear(p(x), H, p(w), H, p(pack), p(y), H, N, H, H, prec, st)
         elif what == "linear_fp32":
             rc = lib.ggcn_linear(p(x), H, p(w), H, None, p(y), H, N, H, H, 1, st)
         elif what == "aggregate":
