@@ -23,7 +23,8 @@ _ADJ_DTYPES = {
 # `adj` (models/bert_amir5.py:589,626,639) and share one conversion -- and one read-back of the weighted flag.
 _RECENT = []
 _RECENT_MAX = 4
-MASK_MAX_T = 128   # include/ggcn.h GGCN_MASK_MAX_T: largest graph the row-mask (one-launch layer) path takes
+MASK_MAX_T = 256   # include/ggcn.h GGCN_MASK_MAX_T: largest graph the row-mask (one-launch layer) path takes
+MASKS_ONLY_MAX_T = 128   # from_dense: up to here the one-launch layer is the default consumer, the CSR arrays are made on demand
 
 
 def cached_from_dense(adj, binary=None):
@@ -39,7 +40,7 @@ def cached_from_dense(adj, binary=None):
 
 class BatchedCSR:
     """rowptr int32[N+1], colidx int32[cap], vals fp32[cap] or None (binary adjacency),
-    rowmask uint32-as-int32[N * ceil(T/32)] or None (T <= MASK_MAX_T = 128: bit j%32 of word j/32 of node i =
+    rowmask uint32-as-int32[N * ceil(T/32)] or None (T <= MASK_MAX_T = 256: bit j%32 of word j/32 of node i =
     edge i<-j), on one GPU.
 
     Built from a dense adjacency with T <= 128 only the row masks are computed up front (one
@@ -133,7 +134,7 @@ class BatchedCSR:
         sb, sr, sc = adj.stride()
         out = cls(None, None, None, B, T)
         out._dense, out._dense_version = adj, adj._version
-        if T <= MASK_MAX_T:
+        if T <= MASKS_ONLY_MAX_T:
             out.rowmask = torch.empty(n * ((T + 31) // 32), dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.ggcn_rowmask_from_dense(_capi.ptr(adj), _ADJ_DTYPES[adj.dtype], B, T, sb, sr, sc,
@@ -146,10 +147,12 @@ class BatchedCSR:
         colidx = torch.empty(cap, dtype=torch.int32, device=dev)
         vals = None if binary is True else torch.empty(cap, dtype=torch.float32, device=dev)
         ws = torch.empty(max(1, lib.ggcn_csr_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        if T <= MASK_MAX_T:   # 129..256: the same pass leaves the row masks for the 256-row graph slot (fused_max_t = 256)
+            out.rowmask = torch.empty(n * ((T + 31) // 32), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             rc = lib.ggcn_csr_from_dense(_capi.ptr(adj), _ADJ_DTYPES[adj.dtype], B, T, sb, sr, sc,
                                          _capi.ptr(rowptr), _capi.ptr(colidx), _capi.ptr(vals), cap,
-                                         None, _capi.ptr(flags), _capi.ptr(ws), _capi.stream_of(dev))
+                                         _capi.ptr(out.rowmask), _capi.ptr(flags), _capi.ptr(ws), _capi.stream_of(dev))
         _capi.check(rc, "ggcn_csr_from_dense")
         if binary is None and not (int(flags.item()) & _capi.FLAG_WEIGHTED):
             vals = None

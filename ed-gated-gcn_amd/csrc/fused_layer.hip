@@ -349,7 +349,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
     GGCN_TRACE(6);
 }
 
-// ---- graphs of 33..128 nodes (LitBank: ORI_ML = 100, constant.py:227) in the same one launch per layer ----
+// ---- graphs of 33..256 nodes (LitBank: ORI_ML = 100, constant.py:227; ACE cased: ORI_ML = 231, constant.py:267)
+// in the same one launch per layer ----
 // A graph occupies SB = 2 or 4 consecutive 32-row blocks of a wavefront's 128-row tile (64- or 128-row slot;
 // T in 65..96 takes the 128-row slot), its adjacency is SB x SB blocks of 32 x 32 bits (row masks of
 // ceil(T/32) words), and the neighbour sum of output block io is
@@ -357,10 +358,16 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
 // with every hidden[ii] taken from the accumulator tiles as in the 32-node kernel.  All accumulators are first
 // split into their two bf16 planes IN PLACE (same register count), then each output block is produced,
 // normalised, gated, pooled and stored.  One part only (the two-layer block form stays with T <= 32).
+// SB = 8 (T in 129..256): the workgroup runs the main loop TWICE (rows 0-127, then 128-255 of its graph) and keeps
+// the first half's planes in registers meanwhile -- 256 registers of planes in the epilogue, so this variant is
+// built for one wavefront per SIMD (the 512-entry file: arch + accumulation registers) and the main loop runs at
+// its lone-wavefront speed: one launch and no [N,F] round trip of `hidden`, but measured 4-18 % SLOWER than
+// linear + aggregate at T = 231 (tools/wide_timing.py; skipping all-zero adjacency blocks made it slower still), so
+// the host side takes it only on request (GraphConvolution.fused_max_t = 256).
 template <int SCH, bool AVEC, bool KFULL, bool VST, int SB>
-__global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_wide_kernel(const FusedArgs a)
+__global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_fused_wide_kernel(const FusedArgs a)
 {
-    static_assert(SB == 2 || SB == 4, "a graph slot is 64 or 128 rows");
+    static_assert(SB == 2 || SB == 4 || SB == 8, "a graph slot is 64, 128 or 256 rows");
     __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
     const int B = a.B, T = a.T, K = a.K, F = a.F;
     if (a.ov_in && blockIdx.x == 0) reduce_partials(a.ov_in, B * ((F + 63) / 64), B, a.ov_out, reinterpret_cast<float *>(lds));
@@ -372,7 +379,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_wide_kern
     float *__restrict__ out = lp.out, *__restrict__ pool_a = lp.pool_a, *__restrict__ pool_b = lp.pool_b;
     float *__restrict__ ov_partial = lp.ov_partial;
     const int ldo = lp.ldo;
-    constexpr int S = 32 * SB, GPT = 4 / SB;      // rows per graph slot, graphs per wavefront tile
+    constexpr int S = 32 * SB;                     // rows per graph slot
+    constexpr int GPT = SB >= 4 ? 1 : 4 / SB;      // graphs per workgroup
+    constexpr int HALVES = SB == 8 ? 2 : 1;        // 128-row passes through the main loop
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -384,21 +393,30 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_wide_kern
     const int W = (T + 31) >> 5;
 
     constexpr int NP = Geom<float>::NP;
-    const float *arow[NP];
-    bool avalid[NP];
+    // every accumulator tile -> its two bf16 planes (B-operand fragments of the aggregation MFMAs), in place
+    bf16x8 hf[4 * HALVES][RN][2][2];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int row = stage_row<float>(i);
-        const int g = g0 + row / S, r = row % S;
-        avalid[i] = (g < B) && (r < T);
-        const int64_t node = avalid[i] ? (int64_t)g * T + r : 0;
-        arow[i] = a.X + node * a.ldx;
+    for (int hh = 0; hh < HALVES; ++hh) {
+        const float *arow[NP];
+        bool avalid[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = stage_row<float>(i) + 128 * hh;
+            const int g = g0 + row / S, r = row % S;
+            avalid[i] = (g < B) && (r < T);
+            const int64_t node = avalid[i] ? (int64_t)g * T + r : 0;
+            arow[i] = a.X + node * a.ldx;
+        }
+        f32x16 acc[4][RN];
+        if constexpr (SCH == 0)
+            bx3::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps, wm, nt0, n_tiles_total, lds, acc);
+        else
+            mx8::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) split2(acc[i][j], hf[4 * hh + i][j]);
     }
-    f32x16 acc[4][RN];
-    if constexpr (SCH == 0)
-        bx3::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps, wm, nt0, n_tiles_total, lds, acc);
-    else
-        mx8::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
 
     const int c = lane & 31, h = lane >> 5;
     float vb[RN], vsg[GPT][RN], vga[GPT][RN], vgb[GPT][RN];
@@ -422,13 +440,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_wide_kern
             }
         }
     }
-    // every accumulator tile -> its two bf16 planes (B-operand fragments of the aggregation MFMAs), in place
-    bf16x8 hf[4][RN][2][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < RN; ++j) split2(acc[i][j], hf[i][j]);
-
     float *stage_lds = reinterpret_cast<float *>(lds) + wave * (32 * 64);
     const int perm_base = 16 * h;
     const int lane_off = 4 * h * ldo + c;
@@ -439,18 +450,25 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_wide_kern
         for (int s = 0; s < GPT; ++s) {
             const int g = g0 + s;
             if (g >= B) break;  // workgroup-uniform
-            // this lane's adjacency rows: node 32*io + (lane & 31), word ii, for the whole graph: one latency
-            uint32_t mw[SB][SB];
-#pragma unroll
-            for (int io = 0; io < SB; ++io) {
+            // this lane's adjacency rows: node 32*io + (lane & 31), word ii; SB <= 4: for the whole graph (one
+            // latency), SB = 8: one output block ahead (64 words would not stay in registers)
+            constexpr int MB = SB == 8 ? 2 : SB;
+            uint32_t mw[MB][SB];
+            auto load_masks = [&](int io, uint32_t (&m)[SB]) {
                 const int node = 32 * io + c;
                 const bool ok = node < T;
 #pragma unroll
                 for (int ii = 0; ii < SB; ++ii) {
                     const bool okw = ok && ii < W;
-                    const uint32_t m = a.rowmask[okw ? ((int64_t)g * T + node) * W + ii : 0];
-                    mw[io][ii] = okw ? m : 0u;
+                    const uint32_t v = a.rowmask[okw ? ((int64_t)g * T + node) * W + ii : 0];
+                    m[ii] = okw ? v : 0u;
                 }
+            };
+            if constexpr (SB == 8) {
+                load_masks(0, mw[0]);
+            } else {
+#pragma unroll
+                for (int io = 0; io < SB; ++io) load_masks(io, mw[io]);
             }
             float vmax[RN], vmin[RN];
 #pragma unroll
@@ -459,12 +477,15 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_wide_kern
             for (int io = 0; io < SB; ++io) {
                 const int node0 = 32 * io;
                 if (node0 >= T) break;  // workgroup-uniform: block of padding rows
+                const int mi = SB == 8 ? (io & 1) : io;
+                if constexpr (SB == 8)
+                    if (io + 1 < SB) load_masks(io + 1, mw[(io + 1) & 1]);   // rows past T read as zeros
                 int deg = 0;
                 bf16x8 af[SB][2];
 #pragma unroll
                 for (int ii = 0; ii < SB; ++ii) {
-                    deg += __popc(mw[io][ii]);
-                    expand_mask(mw[io][ii] >> (4 * h), af[ii]);
+                    deg += __popc(mw[mi][ii]);
+                    expand_mask(mw[mi][ii] >> (4 * h), af[ii]);
                 }
                 const float inv = 1.0f / (float)(deg + 1);                  // gcn.py:35
                 float rinv[16];
@@ -591,7 +612,7 @@ __global__ __launch_bounds__(256) void rowmask_kernel(const int32_t *__restrict_
     if (i >= n) return;
     const int64_t base = i / T * T;
     const int W = (T + 31) >> 5;
-    uint32_t m[GGCN_MASK_MAX_T / 32] = {0u, 0u, 0u, 0u};
+    uint32_t m[GGCN_MASK_MAX_T / 32] = {};
     for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
         const uint32_t j = (uint32_t)(colidx[e] - base);
 #pragma unroll
@@ -635,9 +656,10 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
     const bool kfull = (a.K % BK == 0);
     a.k_steps = round_up(a.K, BK) / KSTEP;
     a.n_wg = (a.F + BN - 1) / BN;
-    if (a.T > 32) {   // 64- or 128-row graph slots: layer_fused_wide_kernel
-        const int sb = a.T <= 64 ? 2 : 4;
-        const int64_t gt = ((int64_t)a.B + 4 / sb - 1) / (4 / sb);
+    if (a.T > 32) {   // 64-, 128- or 256-row graph slots: layer_fused_wide_kernel
+        const int sb = a.T <= 64 ? 2 : a.T <= 128 ? 4 : 8;
+        const int gpt = sb == 2 ? 2 : 1;   // graphs per workgroup
+        const int64_t gt = ((int64_t)a.B + gpt - 1) / gpt;
         const int64_t gridw = grid_for(gt, a.n_wg);
         if (gridw > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: batch too large", who);
         a.g_tiles = (int)gt;
@@ -650,8 +672,8 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
         else if (fast) GGCN_LAUNCHW(SC, true, true, false, SBV);         \
         else GGCN_LAUNCHW(SC, false, false, false, SBV);                 \
     } while (0)
-        if (precision == GGCN_PREC_F16MX8) { if (sb == 2) GGCN_PICKW(1, 2); else GGCN_PICKW(1, 4); }
-        else { if (sb == 2) GGCN_PICKW(0, 2); else GGCN_PICKW(0, 4); }
+        if (precision == GGCN_PREC_F16MX8) { if (sb == 2) GGCN_PICKW(1, 2); else if (sb == 4) GGCN_PICKW(1, 4); else GGCN_PICKW(1, 8); }
+        else { if (sb == 2) GGCN_PICKW(0, 2); else if (sb == 4) GGCN_PICKW(0, 4); else GGCN_PICKW(0, 8); }
 #undef GGCN_PICKW
 #undef GGCN_LAUNCHW
         return check_launch(who);

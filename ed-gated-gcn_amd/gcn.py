@@ -141,8 +141,11 @@ class GraphConvolution(nn.Module):
         # what the reference's fp32 matmul accepts.  "f16mx8" (26 % faster) is opt-in: opt.ggcn_precision /
         # GGCN_PRECISION, for activations of ordinary magnitude (validate_range() checks a batch).
         self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "bf16x3")
-        # one-launch layer (fused_layer.hip) when the batch allows it: T <= 128, binary adjacency, split precision
+        # one-launch layer (fused_layer.hip) when the batch allows it: T <= fused_max_t, binary adjacency, split
+        # precision.  128 by default: the 256-row graph slot (T in 129..256, e.g. ACE cased's ORI_ML = 231) runs one
+        # wavefront per SIMD and measures 4-18 % slower than linear + aggregate; set 256 to take it anyway.
         self.fused = bool(getattr(opt, "ggcn_fused", True)) and os.environ.get("GGCN_FUSED", "1") != "0"
+        self.fused_max_t = int(getattr(opt, "ggcn_fused_max_t", None) or os.environ.get("GGCN_FUSED_MAX_T", "128"))
         # dense adjacency handed to forward(): None = let the device detect edge weights (one 4-byte
         # read-back per conversion), True = promise 0/1 entries like the reference's (graph.py:66-74)
         # and stay sync-free, False = always keep the values
@@ -264,10 +267,10 @@ class GraphConvolution(nn.Module):
                                             or any(g is not None and g.requires_grad for g in gates))
 
     def takes_fused_path(self, text, csr):
-        """True when ``forward_gated`` will run as ONE launch (``ggcn_layer_fused``): graphs of <= 128
-        nodes (row masks), 0/1 adjacency, float32 features, a split-precision linear."""
+        """True when ``forward_gated`` will run as ONE launch (``ggcn_layer_fused``): graphs of <= ``fused_max_t``
+        nodes (row masks exist up to 256), 0/1 adjacency, float32 features, a split-precision linear."""
         return (self.fused and self.precision in _capi.PACKED and csr.rowmask is not None and csr.is_binary
-                and text.dtype == torch.float32)
+                and csr.T <= self.fused_max_t and text.dtype == torch.float32)
 
     def forward_gated(self, text, adj, store_gate=None, pool_gate_a=None, pool_gate_b=None,
                       want_out=True, want_pool_a=False, want_pool_b=False, _internal=False,

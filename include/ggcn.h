@@ -21,7 +21,7 @@
  *  - batched CSR: rowptr int32[N+1], colidx int32[nnz] holding GLOBAL node ids
  *    (block-diagonal: every id of row i lies in i's own graph), vals fp32[nnz]
  *    or NULL for a binary adjacency (all ones);
- *  - row masks (graphs of at most GGCN_MASK_MAX_T = 128 nodes): rowmask uint32[N][W], W = ceil(T/32) words
+ *  - row masks (graphs of at most GGCN_MASK_MAX_T = 256 nodes): rowmask uint32[N][W], W = ceil(T/32) words
  *    per node, bit j%32 of word j/32 of node b*T+i set iff adj[b,i,j] != 0 -- the 0/1 adjacency at one bit
  *    per entry (T <= 32: one word per node), consumed by ggcn_layer_fused / ggcn_block_fused.
  */
@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define GGCN_ABI_VERSION 5
-#define GGCN_MASK_MAX_T 128   /* largest graph the row-mask (one-launch) path takes */
+#define GGCN_MASK_MAX_T 256   /* largest graph the row-mask (one-launch) path takes */
 
 typedef void *ggcn_stream_t;
 
@@ -207,7 +207,7 @@ int ggcn_aggregate_h(const void *Hd, int64_t ldh,
                      void *out, int64_t ldo, float *pool_a, float *pool_b,
                      ggcn_stream_t stream);
 
-/* ---- one whole gated layer in one launch (graphs of <= GGCN_MASK_MAX_T = 128 nodes, binary adjacency) ----
+/* ---- one whole gated layer in one launch (graphs of <= GGCN_MASK_MAX_T = 256 nodes, binary adjacency) ----
  * Replaces models/gcn.py:34-45 + models/bert_amir5.py:627-640 without materialising
  * `hidden`: the linear's accumulator tile (one graph x 32 features) is multiplied by
  * the graph's 0/1 adjacency with a second MFMA, then divided, biased, gated, pooled and

@@ -52,6 +52,7 @@ def _layer(pkg, dev, w, b, precision, fused=True):
     m = pkg.GraphConvolution(w.shape[0], w.shape[1], opt=None, bias=b is not None).to(dev)
     m.precision = precision
     m.fused = bool(fused)
+    m.fused_max_t = 256          # the tests exercise the 256-row graph slot too (the product default is 128)
     with torch.no_grad():
         m.weight.copy_(torch.from_numpy(w))
         if b is not None:
@@ -94,15 +95,15 @@ def test_csr_from_dense_bit_exact(pkg, dev, dtype):
 
 def test_csr_weighted_and_large_t(pkg, dev):
     rng = np.random.default_rng(11)
-    adj = (rng.random((3, 200, 200)) < 0.03).astype(np.float32) * rng.uniform(0.5, 2, (3, 200, 200)).astype(np.float32)
-    adj[:, np.arange(200), np.arange(200)] = 1.0
+    adj = (rng.random((3, 300, 300)) < 0.03).astype(np.float32) * rng.uniform(0.5, 2, (3, 300, 300)).astype(np.float32)
+    adj[:, np.arange(300), np.arange(300)] = 1.0
     rowptr, colidx, vals = csr_ref.csr_from_dense(adj)
     csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj).to(dev))
     nnz = int(rowptr[-1])
     assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
     assert np.array_equal(csr.colidx[:nnz].cpu().numpy(), colidx)
     assert np.array_equal(csr.vals[:nnz].cpu().numpy(), vals)   # weights detected -> values kept
-    assert csr.rowmask is None                                   # T > 128: no row masks
+    assert csr.rowmask is None                                   # T > 256: no row masks
 
 
 def test_csr_scan_across_many_tiles(pkg, dev):
@@ -1178,9 +1179,9 @@ def test_training_dropout_masks_the_gates_per_token(pkg, dev):
     assert zero_frac < 0.02, "pooled features vanish with probability %.2f: the dropout mask is shared by the tokens" % zero_frac
 
 
-# ---------------------------------------------------------------- one launch per layer for 32 < T <= 128 (LitBank: ORI_ML = 100)
+# ---------------------------------------------------------------- one launch per layer for 32 < T <= 256 (LitBank: ORI_ML = 100, ACE cased: 231)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.uint8, torch.int64])
-@pytest.mark.parametrize("T", [33, 64, 65, 100, 128])
+@pytest.mark.parametrize("T", [33, 64, 65, 100, 128, 129, 231, 256])
 def test_wide_row_masks_bit_exact(pkg, dev, T, dtype):
     """ceil(T/32) mask words per node from the dense slice (one kernel), from a CSR (ggcn_csr_rowmask) and from
     the host collation agree with numpy bit for bit."""
@@ -1212,9 +1213,10 @@ def test_wide_row_masks_bit_exact(pkg, dev, T, dtype):
 @pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
 @pytest.mark.parametrize("B,T,K,F,padded", [(5, 100, 256, 256, True), (9, 64, 768, 768, False), (3, 33, 72, 40, True),
                                             (4, 128, 300, 300, False), (6, 96, 64, 512, True), (2, 65, 9, 13, True),
-                                            (17, 48, 128, 128, True)])
+                                            (17, 48, 128, 128, True), (5, 231, 256, 256, True), (3, 256, 768, 768, False),
+                                            (4, 129, 72, 40, True), (2, 200, 9, 13, True), (7, 160, 300, 520, True)])
 def test_wide_graph_layer_one_launch_vs_oracle(pkg, dev, precision, B, T, K, F, padded):
-    """ggcn_layer_fused on graphs of 33..128 nodes (64- / 128-row slots, SB x SB adjacency blocks) against the
+    """ggcn_layer_fused on graphs of 33..256 nodes (64- / 128- / 256-row slots, SB x SB adjacency blocks) against the
     oracle (gcn.py:30-45 + both gates and pools), against the unfused path, and through a host-collated CSR."""
     from ed_gated_gcn_amd import synth
     rng = np.random.default_rng(B * T + F)
@@ -1246,12 +1248,14 @@ def test_wide_graph_layer_one_launch_vs_oracle(pkg, dev, precision, B, T, K, F, 
     assert pools_only[0] is None and torch.equal(pools_only[1], got[1]) and torch.equal(pools_only[2], got[2])
 
 
+@pytest.mark.parametrize("T", [100, 231], ids=["litbank", "ace-cased"])
 @pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
-def test_wide_graph_block_litbank_shape(pkg, dev, precision):
-    """The gated block at LitBank's shape (constant.py:227: ORI_ML = 100; hidden 256): two one-launch layers,
-    xy folded into them, against the oracle block; training through the same path gives the oracle's gradients."""
+def test_wide_graph_block_litbank_shape(pkg, dev, precision, T):
+    """The gated block at LitBank's shape (constant.py:227: ORI_ML = 100; hidden 256) and at ACE cased's
+    (constant.py:267: ORI_ML = 231): two one-launch layers, xy folded into them, against the oracle block;
+    training through the same path gives the oracle's gradients."""
     from ed_gated_gcn_amd import synth
-    B, T, H = 12, 100, 256
+    B, H = 12, 256
     rng = np.random.default_rng(7)
     adj = synth.dependency_batch(B, T, 3.5, seed=3, lengths=rng.integers(10, T + 1, size=B))
     x = rng.standard_normal((B, T, H)).astype(np.float32)
@@ -1261,6 +1265,7 @@ def test_wide_graph_block_litbank_shape(pkg, dev, precision):
     ref = _oracle_block(x, adj.astype(np.float32), g1, g2, w1, b1, w2, b2)
     gc1, gc2 = _layer(pkg, dev, w1, b1, precision), _layer(pkg, dev, w2, b2, precision)
     td = lambda a: torch.from_numpy(a).to(dev)
+    assert gc1.takes_fused_path(td(x), pkg.BatchedCSR.from_dense(td(adj)))
     with torch.no_grad():
         r = pkg.gated_gcn_block(td(x), td(adj), td(g1), td(g2), gc1, gc2, want_gcn1=True)
     for k in ("gcn1", "x1", "y1", "x", "out"):

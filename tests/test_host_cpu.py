@@ -132,9 +132,9 @@ def test_from_arrays_validates():
     wide = BatchedCSR.from_arrays(rp, ci, 1, 40, "cpu").rowmask.numpy().view(np.uint32).reshape(40, 2)   # 2 words per node
     bits = ((wide[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(40, 64)[:, :40]
     assert np.array_equal(bits, (big[0] != 0).astype(np.uint32))
-    huge = synth.dependency_batch(1, 130, 3.0)
+    huge = synth.dependency_batch(1, 260, 3.0)
     rp, ci, _ = synth.csr_from_dense_host(huge)
-    assert BatchedCSR.from_arrays(rp, ci, 1, 130, "cpu").rowmask is None   # T > 128: no masks
+    assert BatchedCSR.from_arrays(rp, ci, 1, 260, "cpu").rowmask is None   # T > 256: no masks
 
 
 def test_graph_batcher_matches_dense_slice():
