@@ -361,8 +361,8 @@ def main():
     step_pool = make_events(args.steps + 1)
     torch.cuda.synchronize(dev)
     if graphs is None:
-        for name in ("ggcn_block_fused", "ggcn_layer_fused", "ggcn_linear", "ggcn_linear_h", "ggcn_aggregate",
-                     "ggcn_aggregate_h"):
+        for name in ("ggcn_block_fused", "ggcn_layer_fused", "ggcn_layer_fused_h", "ggcn_linear", "ggcn_linear_h",
+                     "ggcn_aggregate", "ggcn_aggregate_h"):
             hooked[name], w = with_events(name)
             setattr(lib, name, w)
     sync_all()
@@ -431,6 +431,11 @@ def main():
         roofline = mfma_line("layer_fused_kernel (block form: both layers of the block in one launch)",
                              "block_fused_kernel:" + args.precision, t, 2 * (lin_flops + agg_flops), fwd_bytes,
                              "one launch per step = 2 layers: 2 x (2*N*K*F + 2*nnz*F) flops, 2 x SURVEY 8(d) bytes")
+    elif "ggcn_layer_fused_h" in kern_us:
+        t = statistics.mean(kern_us["ggcn_layer_fused_h"])
+        roofline = mfma_line("layer_fused_long_kernel (fp16 linear + LDS neighbour sums, one launch per layer)",
+                             "layer_fused_long_kernel:" + args.precision, t, lin_flops + agg_flops, layer_bytes,
+                             "one launch per layer")
     elif "ggcn_layer_fused" in kern_us:
         t = statistics.mean(kern_us["ggcn_layer_fused"])
         roofline = mfma_line("layer_fused_kernel", "layer_fused_kernel:" + args.precision, t, lin_flops + agg_flops,

@@ -51,11 +51,13 @@ PROTOTYPES = {
     "ggcn_linear_h": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_aggregate_h": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                  c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "ggcn_layer_fused_h": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                   c_vp, c_i64, c_vp, c_vp, c_vp]),
     "ggcn_overlap_workspace_bytes": (c_sz, [c_i32]),
     "ggcn_gate_overlap": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2, "f16": 3}
 PACKED = ("bf16x3", "f16mx8", "f16")  # precisions whose linear reads a ggcn_weight_pack image ("f16": half features only)
 FLAG_WEIGHTED = 1

@@ -157,6 +157,15 @@ int ggcn_aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const i
                        ldo, pool_a, pool_b, as_stream(stream));
 }
 
+int ggcn_layer_fused_h(const void *X, int64_t ldx, const void *wpack, const int32_t *rowptr, const int32_t *colidx,
+                       const float *vals, const float *bias, int B, int T, int K, int F, const float *store_gate,
+                       const float *pool_gate_a, const float *pool_gate_b, void *out, int64_t ldo, float *pool_a,
+                       float *pool_b, ggcn_stream_t stream)
+{
+    return layer_fused_h(X, ldx, wpack, rowptr, colidx, vals, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b,
+                         out, ldo, pool_a, pool_b, as_stream(stream));
+}
+
 int ggcn_gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                             const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                             const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,

@@ -54,6 +54,11 @@ int aggregate_h(const void *Hd, int64_t ldh, const int32_t *rowptr, const int32_
                 const float *bias, int B, int T, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, void *out, int64_t ldo, float *pool_a, float *pool_b, hipStream_t st);
 
+int layer_fused_h(const void *X, int64_t ldx, const void *wpack, const int32_t *rowptr, const int32_t *colidx,
+                  const float *vals, const float *bias, int B, int T, int K, int F, const float *store_gate,
+                  const float *pool_gate_a, const float *pool_gate_b, void *out, int64_t ldo, float *pool_a,
+                  float *pool_b, hipStream_t st);
+
 int aggregate(const float *Hd, int64_t ldh, const int32_t *rowptr, const int32_t *colidx,
               const float *vals, const float *bias, int B, int T, int F, const float *store_gate,
               const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,

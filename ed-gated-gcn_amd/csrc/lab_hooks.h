@@ -32,3 +32,19 @@ __device__ unsigned long long ggcn_trace_buf[8192 * 8];
 #define GGCN_TRACE_IDS() do { } while (0)
 #define GGCN_TRACE_READER
 #endif
+
+// the same for layer_fused_long_kernel (fused_long.hip; tools/long_trace.py, build flag -DGGCN_LAB_TRACE_LONG)
+#ifdef GGCN_LAB_TRACE_LONG
+__device__ unsigned long long ggcn_trace_long[4096 * 8];
+#define GGCN_LT(slot) do { if (threadIdx.x == 0 && blockIdx.x < 4096) ggcn_trace_long[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#define GGCN_LT_WAVE7(slot) do { if (threadIdx.x == 448 && blockIdx.x < 4096) ggcn_trace_long[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#define GGCN_LT_READER                                                                                    \
+    extern "C" int ggcn_lab_trace_read_long(void *dst, size_t bytes)                                      \
+    {                                                                                                     \
+        return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ggcn_trace_long), bytes, 0, hipMemcpyDeviceToHost); \
+    }
+#else
+#define GGCN_LT(slot) do { } while (0)
+#define GGCN_LT_WAVE7(slot) do { } while (0)
+#define GGCN_LT_READER
+#endif

@@ -272,6 +272,15 @@ class GraphConvolution(nn.Module):
         return (self.fused and self.precision in _capi.PACKED and csr.rowmask is not None and csr.is_binary
                 and csr.T <= self.fused_max_t and text.dtype == torch.float32)
 
+    LONG_MAX_T = 512   # include/ggcn.h GGCN_LONG_MAX_T
+
+    def takes_long_path(self, text, csr):
+        """True when ``forward_gated`` will run as ONE launch of ``ggcn_layer_fused_h``: half features with
+        ``precision="f16"``, graphs of 129..512 nodes (shorter ones leave most of the 512 row slots empty and stay
+        with linear + aggregate), K % 64 == 0, F % 8 == 0."""
+        return (self.fused and self.precision == "f16" and text.dtype == torch.float16
+                and 128 < csr.T <= self.LONG_MAX_T and self.in_features % 64 == 0 and self.out_features % 8 == 0)
+
     def forward_gated(self, text, adj, store_gate=None, pool_gate_a=None, pool_gate_b=None,
                       want_out=True, want_pool_a=False, want_pool_b=False, _internal=False,
                       overlap_partial=None, overlap_reduce=None):
@@ -316,7 +325,8 @@ class GraphConvolution(nn.Module):
         use_fused = self.takes_fused_path(text, csr)
         if (overlap_partial is not None or overlap_reduce is not None) and not use_fused:
             raise RuntimeError("overlap_partial / overlap_reduce need the one-launch layer (takes_fused_path)")
-        hidden = None if use_fused else self.linear(x2d)
+        use_long = (not use_fused) and self.takes_long_path(text, csr) and x2d.data_ptr() % 16 == 0
+        hidden = None if (use_fused or use_long) else self.linear(x2d)
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
             out = torch.empty(B * T, F, dtype=text.dtype, device=dev) if want_out else None
@@ -334,6 +344,14 @@ class GraphConvolution(nn.Module):
                                                  _capi.ptr(overlap_reduce[1]) if overlap_reduce else None,
                                                  _capi.PREC[self.precision], st),
                             "ggcn_layer_fused")
+                return (None if out is None else out.view(B, T, F)), pa, pb
+            if use_long:   # long fp16 graphs (BASELINE configs[3]): linear + aggregation in one launch, hidden stays in LDS
+                pack = self._packed_weight(lib, st)
+                _capi.check(lib.ggcn_layer_fused_h(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack), _capi.ptr(csr.rowptr),
+                                                   _capi.ptr(csr.colidx), _capi.ptr(csr.vals), _capi.ptr(bias), B, T,
+                                                   self.in_features, F, _capi.ptr(store_gate), _capi.ptr(pool_gate_a),
+                                                   _capi.ptr(pool_gate_b), _capi.ptr(out), F, _capi.ptr(pa), _capi.ptr(pb), st),
+                            "ggcn_layer_fused_h")
                 return (None if out is None else out.view(B, T, F)), pa, pb
             agg = lib.ggcn_aggregate_h if half else lib.ggcn_aggregate
             _capi.check(agg(_capi.ptr(hidden), hidden.stride(0), _capi.ptr(csr.rowptr),

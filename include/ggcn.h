@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 5
+#define GGCN_ABI_VERSION 6
 #define GGCN_MASK_MAX_T 256   /* largest graph the row-mask (one-launch) path takes */
 
 typedef void *ggcn_stream_t;
@@ -206,6 +206,21 @@ int ggcn_aggregate_h(const void *Hd, int64_t ldh,
                      const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
                      void *out, int64_t ldo, float *pool_a, float *pool_b,
                      ggcn_stream_t stream);
+
+/* The two calls above as ONE launch for long graphs (T <= GGCN_LONG_MAX_T = 512) with fp16 features: models/gcn.py:34-45
+ * (+ the gates and pools of models/bert_amir5.py:627-640) without `hidden` leaving the CU.  A workgroup owns a
+ * graph and 128 output columns: plain fp16 MFMA (the arithmetic of GGCN_PREC_F16; wpack from
+ * ggcn_weight_pack(..., GGCN_PREC_F16)), `hidden` rounded to fp16 into LDS exactly as ggcn_linear_h stores it, then the
+ * CSR neighbour sums out of LDS.  Same arguments and results as ggcn_linear_h(GGCN_PREC_F16) + ggcn_aggregate_h
+ * (rounding of the fp32 sums differs by summation order only).  Needs K % 64 == 0, F % 8 == 0, 16-byte aligned
+ * X / out / bias / gates with ldx, ldo multiples of 8; anything else returns GGCN_EUNSUPPORTED (use the two calls). */
+#define GGCN_LONG_MAX_T 512
+int ggcn_layer_fused_h(const void *X, int64_t ldx, const void *wpack,
+                       const int32_t *rowptr, const int32_t *colidx, const float *vals,
+                       const float *bias, int B, int T, int K, int F,
+                       const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
+                       void *out, int64_t ldo, float *pool_a, float *pool_b,
+                       ggcn_stream_t stream);
 
 /* ---- one whole gated layer in one launch (graphs of <= GGCN_MASK_MAX_T = 256 nodes, binary adjacency) ----
  * Replaces models/gcn.py:34-45 + models/bert_amir5.py:627-640 without materialising

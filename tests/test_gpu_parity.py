@@ -728,6 +728,71 @@ def test_fp16_long_graphs_lds_slab_form(pkg, dev, T, degree, weighted):
     np.testing.assert_allclose(pb.cpu().numpy(), ref.max(dim=1)[0].numpy(), rtol=0, atol=3e-3)
 
 
+@pytest.mark.parametrize("B,T,K,F,degree,weighted", [(3, 512, 128, 256, 6.0, False), (2, 300, 64, 136, 5.0, True),
+                                                       (9, 129, 192, 128, 4.0, False), (2, 512, 64, 72, 20.0, False),
+                                                       (4, 400, 1024, 1024, 6.0, False)])
+def test_fp16_long_graphs_one_launch(pkg, dev, B, T, K, F, degree, weighted):
+    """ggcn_layer_fused_h (half features, precision "f16", 129..512 nodes): linear + neighbour sums in one launch with
+    `hidden` kept in LDS -- against the oracle on the fp16-rounded inputs (config 4's gate, SURVEY 8d: 2e-3 + the fp16
+    rounding of the output), against the two-launch path of the same precision, with ragged lengths, edge weights,
+    > 4096 edges per graph (indices from global memory), pools only, and the shapes it must refuse."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(T + K)
+    lens = np.array([T] + [int(v) for v in rng.integers(T // 3, T + 1, size=B - 1)])
+    adj = synth.dependency_batch(B, T, min(degree, T), seed=T, lengths=lens).astype(np.float32)
+    if weighted:
+        adj = adj * rng.uniform(0.25, 2.0, size=adj.shape).astype(np.float32)
+    x16 = torch.from_numpy(rng.standard_normal((B, T, K)).astype(np.float32)).half()
+    g1 = torch.from_numpy(rng.uniform(-1.0, 1.0, (B, F)).astype(np.float32))    # negative gates: max picks the other end
+    g2 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32)))
+    w, b = synth.layer_params(K, F, seed=5)
+    ref = ref_dense.graph_convolution(x16.float(), torch.from_numpy(adj), torch.from_numpy(w), torch.from_numpy(b))
+    m, two = _layer(pkg, dev, w, b, "f16"), _layer(pkg, dev, w, b, "f16", fused=False)
+    xd, ad = x16.to(dev), torch.from_numpy(adj).to(dev)
+    csr = pkg.BatchedCSR.from_dense(ad)
+    assert m.takes_long_path(xd, csr) and not two.takes_long_path(xd, csr)
+    kw = dict(store_gate=g2.to(dev), pool_gate_a=g1.to(dev), pool_gate_b=g2.to(dev), want_pool_a=True, want_pool_b=True)
+    with torch.no_grad():
+        out, pa, pb = m.forward_gated(xd, csr, **kw)
+        out2, pa2, pb2 = two.forward_gated(xd, csr, **kw)
+        _, pa3, pb3 = m.forward_gated(xd, csr, pool_gate_a=g1.to(dev), pool_gate_b=g2.to(dev), want_out=False,
+                                      want_pool_a=True, want_pool_b=True)
+    assert out.dtype == torch.float16
+    scale = max(1.0, float(ref.abs().max()))
+    tol = 2e-3 * scale
+    np.testing.assert_allclose(out.float().cpu().numpy(), (ref * g2[:, None, :]).numpy(), rtol=0, atol=tol + scale * 2.0 ** -11)
+    np.testing.assert_allclose(pa.cpu().numpy(), (ref * g1[:, None, :]).max(dim=1)[0].numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(pb.cpu().numpy(), (ref * g2[:, None, :]).max(dim=1)[0].numpy(), rtol=0, atol=tol)
+    # same arithmetic as the two launches (fp16 MFMA, hidden rounded to fp16, fp32 sums): only the summation order differs
+    assert float((out.float() - out2.float()).abs().max()) <= scale * 2.0 ** -10
+    assert float((pa - pa2).abs().max()) <= 1e-4 * scale and float((pb - pb2).abs().max()) <= 1e-4 * scale
+    assert torch.equal(pa3, pa) and torch.equal(pb3, pb)
+
+
+def test_fp16_long_graph_entry_refuses_what_it_cannot_run(pkg, dev):
+    from ed_gated_gcn_amd import _capi, synth
+    lib = pkg.load_library()
+    B, T = 2, 200
+    adj = synth.dependency_batch(B, T, 4.0)
+    rp, ci, _ = synth.csr_from_dense_host(adj)
+    csr = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
+    p, st = _capi.ptr, _capi.stream_of(dev)
+    def call(K, F, T_=T, x_off=0):
+        x = torch.zeros(B * T * K + 8, dtype=torch.float16, device=dev)[x_off:]
+        w = torch.zeros(K, F, device=dev)
+        pack = torch.empty(lib.ggcn_weight_pack_bytes(K, F, 3), dtype=torch.uint8, device=dev)
+        assert lib.ggcn_weight_pack(p(w), F, K, F, 3, 0, p(pack), st) == 0
+        out = torch.empty(B * T, F, dtype=torch.float16, device=dev)
+        return lib.ggcn_layer_fused_h(p(x), K, p(pack), p(csr.rowptr), p(csr.colidx), None, None, B, T_, K, F, None, None,
+                                      None, p(out), F, None, None, st)
+    assert call(64, 64) == 0
+    assert call(96, 64) == 3 and b"K % 64" in lib.ggcn_last_error()
+    assert call(64, 60) == 3
+    assert call(64, 64, x_off=4) == 3          # X not 16-byte aligned
+    assert call(64, 64, T_=513) == 3
+    torch.cuda.synchronize()
+
+
 def test_empty_batch_like_the_reference(pkg, dev):
     """B = 0 is a valid input of gcn.py:30-45 (empty output, no kernel launch); the reference block's mean over
     an empty batch is nan."""
