@@ -4,19 +4,24 @@
 //
 // A workgroup of 8 wavefronts owns (graph, 128 columns): all 512 row slots of the graph, so every source row a
 // neighbour sum can ask for is produced by the SAME workgroup.
-//   1. main loop (plain fp16 MFMA as f16_core.h, fp32 accumulation): wavefront (rg, cg) = 128 rows x 64 columns,
-//      4 row groups x 2 column groups; the 512 x 64-k stage of X is staged by all 512 threads (8 passes of 16 B,
-//      register staging one stage ahead) into a double buffer of 2 x 64 KiB; W fragments come straight from L2
-//      (the fp16 part of the f16mx8 image), the four row groups asking for the same fragments back to back.
+//   1. main loop (plain fp16 MFMA, the arithmetic of f16_core.h, fp32 accumulation): wavefront (rg, cg) = 128 rows x
+//      64 columns, 4 row groups x 2 column groups.  Both operands reach LDS by LDS-DMA (global_load_lds: no staging
+//      registers, no ds_write pass): the X stage is [512 rows][128 B] per buffer with the 16-byte chunk XORed by
+//      (row >> 1) & 7 -- applied to the SOURCE address, a DMA piece being 8 rows x 128 B = 1 KiB lane-linear in LDS --
+//      and the W fragments of the stage (16 x 1 KiB, already in lane order in the packed image: the fp16 part of the
+//      f16mx8 records) go through LDS as well, fetched once for the four row groups.  Two buffers of 64 + 16 KiB = all
+//      160 KiB; a stage's ten pieces per wavefront leave one stage ahead, behind the first MFMAs; the stage ends in
+//      vmcnt(0) + barrier.
 //   2. the accumulators are rounded to fp16 -- the same rounding `hidden` gets on the two-launch path -- and
-//      written over the dead stage buffers: the graph's hidden tile [512][128] fp16 = 128 KiB of LDS.
+//      written over the dead X buffers: the graph's hidden tile [512][128] fp16 = 128 KiB of LDS.
 //   3. neighbour sums out of LDS as in aggregate_narrow (aggregate.hip): the graph's CSR (row pointers, 16-bit
-//      local column ids) was staged at kernel start; 8 lanes x 32 B cover a row of the tile, a wavefront works on
-//      8 destination rows at once with 8 source rows each in flight; normalise, bias, gate, fp16 row stores, running
-//      max / min in registers meeting in LDS at the end (one workgroup sees all rows of its graph: no atomics).
+//      local column ids; held in registers during the main loop, stored where the W buffers were); 8 lanes x 32 B cover
+//      a row of the tile, a wavefront works on 8 destination rows at once with 8 source rows each in flight;
+//      normalise, bias, gate, fp16 row stores, running max / min in registers meeting in LDS at the end (one
+//      workgroup sees all rows of its graph: no atomics).
 // HBM traffic = X in + out + CSR + W: the algorithmic bytes of SURVEY 8(d) (the 2 x 268 MB round trip of
-// `hidden` at config 4 is gone).  LDS: 128 KiB tile + 10 KiB CSR + 16 KiB pool scratch: one workgroup per CU,
-// two wavefronts per SIMD -- the occupancy of the two-launch linear.
+// `hidden` at config 4 is gone).  One workgroup per CU, two wavefronts per SIMD -- the occupancy of the two-launch
+// linear.
 #include "f16mx8_core.h"
 #include "lab_hooks.h"
 
@@ -26,22 +31,22 @@ namespace {
 using namespace bx3;
 using mx8::f16x8;
 
-constexpr int LR = 512;                     // row slots per workgroup (= kLongMaxT)
+constexpr int LR = 512;                     // row slots per workgroup (GGCN_LONG_MAX_T)
 constexpr int LC = 128;                     // columns per workgroup
 constexpr int LTHR = 512;                   // threads: 8 wavefronts
 constexpr int LBK = 64;                     // k per stage
-constexpr int LNP = 8;                      // staging passes: 512 rows x 128 B = 4096 pieces of 16 B / 512 threads
-constexpr int kPlane = LR * ROWB;           // one k-half of a stage: [512 rows][64 B] = 32 KiB
-constexpr int kStage = 2 * kPlane;          // 64 KiB
-constexpr int kTile = 2 * kStage;           // double buffer = the hidden tile afterwards: 128 KiB
+constexpr int kDmaA = LR * 2 * LBK;         // X stage buffer: [512 rows][128 B] = 64 KiB
+constexpr int kDmaB = (LC / NT) * (LBK / KSTEP) * FRAG_BYTES;   // W stage buffer: 4 column tiles x 4 k-steps x 1 KiB = 16 KiB
+constexpr int kTile = 2 * kDmaA;            // the two X buffers = the hidden tile afterwards: 128 KiB
+constexpr int kDmaLds = kTile + 2 * kDmaB;  // 160 KiB: everything a CU has
 constexpr int kIdxCapL = 4096;              // staged column ids per graph (more: read from global memory)
+// after the main loop, where the W buffers were:
 constexpr int kOffRp = kTile + LC * 2;                          // (row LR of the tile: all zeros) int[LR + 1]
-constexpr int kOffCol = kOffRp + ((LR + 1) * 4 + 15) / 16 * 16; // unsigned short[kIdxCapL]
-constexpr int kOffRed = kOffCol + (kIdxCapL + 8) * 2;           // (8 spare ids: the 8-wide reads overrun a row) float[2][16][LC]
-constexpr int kLongLds = kOffRed + 2 * 16 * LC * 4;
+constexpr int kOffCol = kOffRp + ((LR + 1) * 4 + 15) / 16 * 16; // unsigned short[kIdxCapL + 8] (8 spare ids: the 8-wide reads overrun a row)
+constexpr int kOffRed = kOffCol + (kIdxCapL + 8) * 2;           // float[2][16][LC]
+static_assert(kOffRed + 2 * 16 * LC * 4 <= kDmaLds, "the epilogue's LDS map must fit where the W buffers were");
 
 #define GGCN_SB() __builtin_amdgcn_sched_barrier(0)
-
 
 // hidden tile: row r at r * 256 B, plain.  A ds_read_b128 is served in four groups of 16 lanes made of {4, 4, 8}
 // lanes of two neighbouring 16-lane rows (MI355X_MICROARCH.md, LDS): with one tile row per 16 lanes every group covers
@@ -100,63 +105,28 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
     const int rg = wave >> 1, cg = wave & 1;
     const int64_t node0 = (int64_t)b * T;
     const int n_tiles_total = (F + NT - 1) / NT;
-    const int nt0 = ct * (LC / NT) + cg * RN;
     const int stages = K / LBK;             // the launcher guarantees K % 64 == 0
 
     GGCN_LT(0);
-    // ---- the graph's CSR leaves for LDS (read again only after the main loop's barriers) ----
+    // ---- the graph's CSR ----
     const int e_base = a.rowptr[node0];
     const int nnz_g = a.rowptr[node0 + T] - e_base;
     const bool staged = nnz_g <= kIdxCapL;  // workgroup-uniform
-    for (int i = tid; i <= T; i += LTHR) s_rp[i] = a.rowptr[node0 + i] - e_base;
-    if (staged)
-        for (int j = tid; j < nnz_g; j += LTHR) s_col[j] = (unsigned short)(a.colidx[e_base + j] - (int)node0);
+    // the W buffers occupy the CSR's place during the main loop: the CSR waits in registers (unconditional loads from
+    // clamped indices: a branch per load would serialise eight memory latencies)
+    int rp_reg = a.rowptr[node0 + (tid < T ? tid : 0)] - e_base;
+    unsigned short col_reg[kIdxCapL / LTHR];
+    {
+        const int32_t *cbase = nnz_g > 0 ? a.colidx + e_base : a.rowptr + node0;
+        const int last = nnz_g > 0 ? nnz_g - 1 : 0;
+#pragma unroll
+        for (int j = 0; j < kIdxCapL / LTHR; ++j) {
+            const int idx = tid + LTHR * j;
+            col_reg[j] = (unsigned short)(cbase[idx < last ? idx : last] - (int)node0);
+        }
+    }
 
     // ---- 1. hidden = X . W ----
-    const int piece = tid & 7;              // 16-byte piece of a row's 128 B: k = 8 piece .. 8 piece + 7
-    const int s_row = tid >> 3;             // + 64 per pass
-    const __half *arow[LNP];
-    bool avalid[LNP];
-#pragma unroll
-    for (int p = 0; p < LNP; ++p) {
-        const int r = 64 * p + s_row;
-        avalid[p] = FULLT || r < T;
-        arow[p] = a.X + (node0 + (avalid[p] ? r : 0)) * a.ldx + 8 * piece;
-    }
-    uint4 ra[LNP];
-    auto load_a_pass = [&](int p, int st) {
-        st = st < stages ? st : stages - 1;
-        ra[p] = *reinterpret_cast<const uint4 *>(arow[p] + st * LBK);
-    };
-    auto write_pass = [&](int buf, int p) {
-        uint4 v = ra[p];
-        if constexpr (!FULLT)
-            if (!avalid[p]) v = make_uint4(0u, 0u, 0u, 0u);
-        char *plane = lds + buf * kStage + (piece >> 2) * kPlane;
-        *reinterpret_cast<uint4 *>(plane + a_lds_off(64 * p + s_row, piece & 3)) = v;
-    };
-    const char *bbase[RN];
-#pragma unroll
-    for (int j = 0; j < RN; ++j) {
-        const int ntc = nt0 + j < n_tiles_total ? nt0 + j : n_tiles_total - 1;
-        bbase[j] = a.wpack + (int64_t)ntc * a.records * mx8::STAGE_PACK_BYTES + lane * 16;
-    }
-    auto load_b = [&](int r, f16x8 (&bf)[RN][2]) {
-        r = r < a.records ? r : a.records - 1;
-#pragma unroll
-        for (int j = 0; j < RN; ++j) {
-            const char *p = bbase[j] + (int64_t)r * mx8::STAGE_PACK_BYTES;
-            bf[j][0] = *reinterpret_cast<const f16x8 *>(p);
-            bf[j][1] = *reinterpret_cast<const f16x8 *>(p + 1024);
-        }
-    };
-    const int f_row = 128 * rg + (lane & 31), f_half = lane >> 5;
-    auto read_a = [&](int buf, int hh, int i, f16x8 (&af)[2]) {
-        const char *plane = lds + buf * kStage + hh * kPlane;
-        af[0] = *reinterpret_cast<const f16x8 *>(plane + a_lds_off(f_row + 32 * i, f_half));
-        af[1] = *reinterpret_cast<const f16x8 *>(plane + a_lds_off(f_row + 32 * i, 2 + f_half));
-    };
-
     f32x16 acc[4][RN];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -164,70 +134,86 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
         for (int j = 0; j < RN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    f16x8 b0[RN][2], b1[RN][2];
+    {
+        const int khalf = lane >> 5;
+        // sources of this wavefront's 8 X pieces (rows 64 p + 8 wave .. + 7) and 2 W pieces per stage
+        const __half *asrc[8];
 #pragma unroll
-    for (int p = 0; p < LNP; ++p) load_a_pass(p, 0);
-    load_b(0, b0);
-#pragma unroll
-    for (int p = 0; p < LNP; ++p) write_pass(0, p);
-#pragma unroll
-    for (int p = 0; p < LNP; ++p) load_a_pass(p, 1);
-    __syncthreads();
-
-    // One stage = two 32-k halves of 4 row blocks x 4 MFMAs; behind the MFMAs of every (half, row block) go the LDS
-    // store of one staging pass of the next stage and its reload one stage further on.
-    auto stage = [&](int st, auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
-        f16x8 af[2][2];
-        read_a(buf, 0, 0, af[0]);
-        load_b(2 * st + 1, b1);
-        GGCN_SB();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < 3) read_a(buf, 0, i + 1, af[(i + 1) & 1]);
-            else read_a(buf, 1, 0, af[0]);
-            GGCN_SB();
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i & 1][0], b0[0][0], acc[i][0], 0, 0, 0);
-            GGCN_SB();
-            write_pass(buf ^ 1, i);
-            GGCN_SB();
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i & 1][0], b0[1][0], acc[i][1], 0, 0, 0);
-            GGCN_SB();
-            load_a_pass(i, st + 2);
-            GGCN_SB();
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i & 1][1], b0[0][1], acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i & 1][1], b0[1][1], acc[i][1], 0, 0, 0);
-            GGCN_SB();
+        for (int p = 0; p < 8; ++p) {
+            const int row = 64 * p + 8 * wave + (lane >> 3);
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);
+            const int rowc = FULLT ? row : (row < T ? row : T - 1);   // rows past T: any valid memory (never gathered, never stored)
+            asrc[p] = a.X + (node0 + rowc) * a.ldx + 8 * lc;
         }
-        load_b(2 * st + 2, b0);   // b0 is dead: next stage's first record
-        GGCN_SB();
+        const int ntw = ct * (LC / NT) + (wave >> 1);
+        const char *bsrc = a.wpack + (int64_t)(ntw < n_tiles_total ? ntw : n_tiles_total - 1) * a.records * mx8::STAGE_PACK_BYTES + lane * 16;
+        const int bdst = 2 * kDmaA + ((wave >> 1) * 4 + 2 * (wave & 1)) * 1024;
+        auto issue_piece = [&](int t, int st, int buf) {   // t = 0..7: X piece t; 8, 9: the two k-steps of this wavefront's W record
+            st = st < stages ? st : stages - 1;
+            if (t < 8) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc[t] + st * LBK),
+                                                 (__attribute__((address_space(3))) void *)(lds + buf * kDmaA + (64 * t + 8 * wave) * 128), 16, 0, 0);
+            } else {
+                int rec = 2 * st + (wave & 1);
+                rec = rec < a.records ? rec : a.records - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + (int64_t)rec * mx8::STAGE_PACK_BYTES + (t - 8) * 1024),
+                                                 (__attribute__((address_space(3))) void *)(lds + bdst + buf * kDmaB + (t - 8) * 1024), 16, 0, 0);
+            }
+        };
+        const int sw = ((lane & 31) >> 1) & 7;
+        const int aoff = (128 * rg + (lane & 31)) * 128;
+        auto read_a = [&](int buf, int s, int i, f16x8 &af) {
+            af = *reinterpret_cast<const f16x8 *>(lds + buf * kDmaA + aoff + i * 4096 + (((2 * s + khalf) ^ sw) << 4));
+        };
+        auto read_b = [&](int buf, int s, f16x8 (&bf)[RN]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < 3) read_a(buf, 1, i + 1, af[(i + 1) & 1]);
+            for (int j = 0; j < RN; ++j)
+                bf[j] = *reinterpret_cast<const f16x8 *>(lds + 2 * kDmaA + buf * kDmaB + ((2 * cg + j) * 4 + s) * 1024 + 16 * lane);
+        };
+#pragma unroll
+        for (int t = 0; t < 10; ++t) issue_piece(t, 0, 0);
+        __syncthreads();   // (vmcnt(0) + barrier: the pieces of every wavefront have landed)
+        // One stage = 4 k-steps x 4 row blocks x 2 MFMAs; fragments are read one block ahead; the ten pieces of the NEXT
+        // stage leave one at a time behind the first MFMAs (their buffer was last read a stage ago).
+        auto stage = [&](int st, auto bufc) {
+            constexpr int buf = decltype(bufc)::value;
+            constexpr int AH = 2;     // X fragment reads run two steps (of 2 MFMAs) ahead of their use, W fragments of a k-step three
+            f16x8 af[AH + 1], bf[2][RN];
+            read_b(buf, 0, bf[0]);
+#pragma unroll
+            for (int t = 0; t < AH; ++t) read_a(buf, t >> 2, t & 3, af[t]);
             GGCN_SB();
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i & 1][0], b1[0][0], acc[i][0], 0, 0, 0);
-            GGCN_SB();
-            write_pass(buf ^ 1, 4 + i);
-            GGCN_SB();
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i & 1][0], b1[1][0], acc[i][1], 0, 0, 0);
-            GGCN_SB();
-            load_a_pass(4 + i, st + 2);
-            GGCN_SB();
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i & 1][1], b1[0][1], acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i & 1][1], b1[1][1], acc[i][1], 0, 0, 0);
-            GGCN_SB();
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = 4 * s4 + i;
+                    if (t + AH < 16) read_a(buf, (t + AH) >> 2, (t + AH) & 3, af[(t + AH) % (AH + 1)]);
+                    if (i == 1 && s4 < 3) read_b(buf, s4 + 1, bf[(s4 + 1) & 1]);
+                    GGCN_SB();
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t % (AH + 1)], bf[s4 & 1][0], acc[i][0], 0, 0, 0);
+                    GGCN_SB();
+                    if (t < 10) issue_piece(t, st + 1, buf ^ 1);
+                    GGCN_SB();
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t % (AH + 1)], bf[s4 & 1][1], acc[i][1], 0, 0, 0);
+                    GGCN_SB();
+                }
+            __syncthreads();
+        };
+        int st = 0;
+        for (; st + 1 < stages; st += 2) {
+            stage(st, std::integral_constant<int, 0>{});
+            stage(st + 1, std::integral_constant<int, 1>{});
         }
-        __syncthreads();
-    };
-    int st = 0;
-    for (; st + 1 < stages; st += 2) {
-        stage(st, std::integral_constant<int, 0>{});
-        stage(st + 1, std::integral_constant<int, 1>{});
+        if (st < stages) stage(st, std::integral_constant<int, 0>{});
+        // the CSR out of its registers into the W buffers' place (every DMA has landed: the stage's closing barrier)
+        if (tid < T) s_rp[tid] = rp_reg;
+        if (tid == 0) s_rp[T] = nnz_g;
+        if (staged) {
+#pragma unroll
+            for (int j = 0; j < kIdxCapL / LTHR; ++j) s_col[tid + LTHR * j] = col_reg[j];
+        }
     }
-    if (st < stages) stage(st, std::integral_constant<int, 0>{});
-    // (the last stage's stores went to the buffer nobody reads, and landed before its closing barrier)
-
     GGCN_LT(1);
     // ---- 2. hidden -> fp16 -> the LDS tile [512][128] over the stage buffers ----
     // Lane pairs (l, l ^ 1) hold neighbouring columns of the same rows: they swap one register of every pair (r, r + 1)
@@ -432,13 +418,14 @@ int layer_fused_h(const void *X, int64_t ldx, const void *wpack, const int32_t *
     const int64_t grid = ((int64_t)B + 7) / 8 * 8 * a.n_ct;
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: batch too large", who);
     const bool fullt = T == LR;
+    constexpr int kLds = kDmaLds;
 #define GGCN_GO(HV, FT)                                                                                                  \
     do {                                                                                                                 \
         auto kern = layer_fused_long_kernel<HV, FT>;                                                                     \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                kLongLds) != hipSuccess)                                                                 \
-            return fail(GGCN_ELAUNCH, "%s: cannot reserve %d bytes of LDS", who, kLongLds);                              \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(LTHR), kLongLds, st, a);                                     \
+                                kLds) != hipSuccess)                                                                 \
+            return fail(GGCN_ELAUNCH, "%s: cannot reserve %d bytes of LDS", who, kLds);                              \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(LTHR), kLds, st, a);                                     \
     } while (0)
     if (vals && fullt) GGCN_GO(true, true);
     else if (vals) GGCN_GO(true, false);
