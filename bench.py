@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--capture", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a hipGraph (auto: when N > 1, where a shard's kernels are short enough "
                          "for the host launch path to show)")
+    ap.add_argument("--gather", default="logits", choices=["logits", "pooled"],
+                    help="N > 1: what every rank all-gathers per step -- per-shard logits [B_r, 34] = out . Wd (north_star; the "
+                         "out-dependent share of bert_amir5.py:643's dense, 70 KB per rank at 8 GPUs) or the pooled out [B_r, H] itself "
+                         "(1.5 MB per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the alt_precisions / accuracy legs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to "
@@ -249,6 +253,14 @@ def main():
             m.precision = precision
             m.fused = path != "unfused"
 
+    # N > 1: the payload of the path's only collective.  "logits": this rank's [B_r, 34] = out . Wd, the share of the
+    # classifier's dense layer that depends on the block's output (bert_amir5.py:643; 34 = ACE's classes, constant.py:266);
+    # a replicated synthetic Wd, one small GEMM per step inside the timed region.  "pooled": out [B_r, H] itself.
+    N_CLASS = 34
+    head = None
+    if world > 1 and args.gather == "logits":
+        head = (torch.randn(H, N_CLASS, generator=torch.Generator().manual_seed(7)) / H ** 0.5).to(dev)
+
     def forward(xx=None, cc=None, a1=None, a2=None, path=None):
         """One pass of the hot path; returns the dict of outputs (config 4: one gated layer)."""
         xx, cc = (x if xx is None else xx), (csr if cc is None else cc)
@@ -256,12 +268,16 @@ def main():
         if one_layer:
             _, pa, pb = gc1.forward_gated(xx, cc, pool_gate_a=a1, pool_gate_b=a2, want_out=True,
                                           want_pool_a=True, want_pool_b=True)
-            return {"x1": pa, "y1": pb, "out": pa}
-        return pkg.gated_gcn_block(xx, cc, a1, a2, gc1, gc2, one_launch=((path or args.path) == "block"))
+            r = {"x1": pa, "y1": pb, "out": pa}
+        else:
+            r = pkg.gated_gcn_block(xx, cc, a1, a2, gc1, gc2, one_launch=((path or args.path) == "block"))
+        if head is not None:
+            r["payload"] = torch.mm(r["out"], head)
+        return r
 
-    # the path's only collective: all-gather of the per-shard pooled outputs [B_r, H], launched
+    # the path's only collective: all-gather of the per-shard logits [B_r, 34] (or pooled outputs [B_r, H]), launched
     # asynchronously so step i's gather (RCCL's stream, xGMI) overlaps step i+1's kernels
-    gather = shard.PooledGather(counts, H, dev) if world > 1 else None
+    gather = shard.PooledGather(counts, N_CLASS if head is not None else H, dev) if world > 1 else None
     pending = []
     capture = args.capture == "on" or (args.capture == "auto" and world > 1)
     set_mode(args.precision, args.path)
@@ -288,7 +304,7 @@ def main():
                 g.replay()
             counter[0] += 1
             if world > 1:
-                pending.append(gather.start(r["out"]))
+                pending.append(gather.start(r["payload"] if head is not None else r["out"]))
         return r
 
     def sync_all():
@@ -531,7 +547,9 @@ def main():
             "config": {"workload": workload, "graphs_total": B_total, "graphs_per_gpu": counts,
                        "precision": args.precision, "path": path_note, "hipgraph_replay": bool(graphs), "capture_note": capture_note,
                        "precondition_steps": n_pre,
-                       "collective": "all_gather(out[B_r,H]) per step, async (RCCL)" if world > 1 else "none"},
+                       "collective": ("none" if world == 1 else
+                                      "all_gather(logits[B_r,%d] = out[B_r,H] . Wd) per step, async (RCCL)" % N_CLASS if head is not None
+                                      else "all_gather(out[B_r,H]) per step, async (RCCL)")},
             "step_us": dict(per_step, events_every_n_steps=ev_stride,
                             note="HIP events on the launch stream of rank 0 bracketing every step (or every 4 steps, "
                                  "averaged, when a step is short); median, p10, p90 over the K timed steps; "
