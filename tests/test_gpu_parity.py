@@ -769,6 +769,49 @@ def test_fp16_long_graphs_one_launch(pkg, dev, B, T, K, F, degree, weighted):
     assert torch.equal(pa3, pa) and torch.equal(pb3, pb)
 
 
+def test_config4_full_size_properties(pkg, dev):
+    """BASELINE.json configs[3] at full size (256 graphs x 512 tokens, degree 6, hidden 1024, fp16 features) through the
+    one-launch layer: (1) bit-identical to linear + aggregate; (2) graphs are independent -- an 8-graph slice run
+    alone gives the same numbers; (3) that slice equals the oracle on the fp16-rounded inputs; (4) the pools are the
+    max over tokens of gate x what was stored (gate >= 0); (5) doubling the store gate doubles the output exactly."""
+    from ed_gated_gcn_amd import synth
+    B, T, H = 256, 512, 1024
+    adj = synth.dependency_batch(B, T, 6.0)
+    rp, ci, _ = synth.csr_from_dense_host(adj)
+    csr = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
+    gen = torch.Generator().manual_seed(synth.SEED)
+    x = torch.randn(B, T, H, generator=gen).half().to(dev)
+    g1 = torch.sigmoid(torch.randn(B, H, generator=gen)).to(dev)
+    g2 = torch.sigmoid(torch.randn(B, H, generator=gen)).to(dev)
+    w, b = synth.layer_params(H, H, seed=1)
+    one, two = _layer(pkg, dev, w, b, "f16"), _layer(pkg, dev, w, b, "f16", fused=False)
+    assert one.takes_long_path(x, csr)
+    kw = dict(want_pool_a=True, want_pool_b=True)
+    with torch.no_grad():
+        out, pa, pb = one.forward_gated(x, csr, store_gate=g2, pool_gate_a=g1, pool_gate_b=g2, **kw)
+        out2, pa2, pb2 = two.forward_gated(x, csr, store_gate=g2, pool_gate_a=g1, pool_gate_b=g2, **kw)
+        assert torch.equal(out, out2) and torch.equal(pa, pa2) and torch.equal(pb, pb2)          # (1)
+        sl = slice(100, 108)
+        rps, cis, _ = synth.csr_from_dense_host(adj[sl])
+        sub = pkg.BatchedCSR.from_arrays(rps, cis, 8, T, dev)
+        outs, pas, pbs = one.forward_gated(x[sl].contiguous(), sub, store_gate=g2[sl].contiguous(),
+                                           pool_gate_a=g1[sl].contiguous(), pool_gate_b=g2[sl].contiguous(), **kw)
+        assert torch.equal(out[sl], outs) and torch.equal(pa[sl], pas) and torch.equal(pb[sl], pbs)   # (2)
+        plain, _, pmax = one.forward_gated(x, csr, pool_gate_b=g2, want_pool_b=True)                  # no store gate
+        twice, _, _ = one.forward_gated(x, csr, store_gate=2.0 * torch.ones_like(g2))
+    ref = ref_dense.graph_convolution(x[sl].float().cpu(), torch.from_numpy(adj[sl].astype(np.float32)), torch.from_numpy(w),
+                                      torch.from_numpy(b))
+    scale = max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(outs.float().cpu().numpy(), (ref * g2[sl].cpu()[:, None, :]).numpy(), rtol=0,
+                               atol=2e-3 * scale + scale * 2.0 ** -11)                                 # (3)
+    np.testing.assert_allclose(pbs.cpu().numpy(), (ref * g2[sl].cpu()[:, None, :]).max(dim=1)[0].numpy(), rtol=0, atol=2e-3 * scale)
+    # (4) fp32 pools vs the fp16-rounded stored rows: equal up to that rounding
+    assert float((pmax - (plain.float() * g2[:, None, :]).max(dim=1)[0]).abs().max()) <= scale * 2.0 ** -10
+    normal = plain.float().abs() >= 2.0 ** -13      # doubling commutes with the fp16 rounding except among subnormals
+    assert torch.equal(twice.float()[normal], 2.0 * plain.float()[normal])                              # (5)
+    assert float((twice.float() - 2.0 * plain.float()).abs().max()) <= 2.0 ** -23
+
+
 def test_fp16_long_graph_entry_refuses_what_it_cannot_run(pkg, dev):
     from ed_gated_gcn_amd import _capi, synth
     lib = pkg.load_library()
