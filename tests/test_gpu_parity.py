@@ -812,6 +812,40 @@ def test_config4_full_size_properties(pkg, dev):
     assert float((twice.float() - 2.0 * plain.float()).abs().max()) <= 2.0 ** -23
 
 
+def test_fp16_long_graphs_random_shapes_match_two_launches_bitwise(pkg, dev):
+    """The one-launch long-graph layer stages both operands by LDS-DMA behind hand-placed waits: a race would show as
+    a rare wrong tile.  40 random shapes (T 129..512, K multiple of 64, F multiple of 8, ragged lengths, weighted or
+    not, B not a multiple of 8), each compared BIT FOR BIT with linear + aggregate of the same arithmetic, the same
+    launch repeated three times."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        B = int(rng.integers(1, 12))
+        T = int(rng.integers(129, 513))
+        K = 64 * int(rng.integers(1, 9))
+        F = 8 * int(rng.integers(1, 41))
+        deg = float(rng.uniform(2.0, 14.0))
+        weighted = bool(rng.integers(0, 2))
+        lens = rng.integers(T // 4, T + 1, size=B)
+        adj = synth.dependency_batch(B, T, min(deg, T), seed=case, lengths=lens).astype(np.float32)
+        if weighted:
+            adj = adj * rng.uniform(0.25, 2.0, size=adj.shape).astype(np.float32)
+        x = torch.from_numpy(rng.standard_normal((B, T, K)).astype(np.float32)).half().to(dev)
+        g = torch.from_numpy(rng.uniform(-1.0, 1.0, (B, F)).astype(np.float32)).to(dev)
+        w, b = synth.layer_params(K, F, seed=case)
+        one, two = _layer(pkg, dev, w, b, "f16"), _layer(pkg, dev, w, b, "f16", fused=False)
+        csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj).to(dev))
+        assert one.takes_long_path(x, csr), (B, T, K, F)
+        kw = dict(store_gate=g, pool_gate_a=g, pool_gate_b=g.abs(), want_pool_a=True, want_pool_b=True)
+        with torch.no_grad():
+            ref = two.forward_gated(x, csr, **kw)
+            for rep in range(3):
+                got = one.forward_gated(x, csr, **kw)
+                for name, u, v in zip(("out", "pool_a", "pool_b"), got, ref):
+                    assert torch.equal(u, v), "case %d rep %d (B=%d T=%d K=%d F=%d deg=%.1f weighted=%s): %s differs, max %g" % (
+                        case, rep, B, T, K, F, deg, weighted, name, float((u.float() - v.float()).abs().max()))
+
+
 def test_fp16_long_graph_entry_refuses_what_it_cannot_run(pkg, dev):
     from ed_gated_gcn_amd import _capi, synth
     lib = pkg.load_library()
