@@ -22,18 +22,32 @@ _ADJ_DTYPES = {
 # OBJECT (weak reference) and its version counter: gc1 and gc2 of one classifier forward receive the same
 # `adj` (models/bert_amir5.py:589,626,639) and share one conversion -- and one read-back of the weighted flag.
 _RECENT = []
-_RECENT_MAX = 4
+_RECENT_MAX = 2   # gc1 and gc2 of ONE forward share a conversion (promised-binary and flag-checked forms of the same
+                  # tensor are two entries); older batches must not stay pinned: a cached BatchedCSR keeps its dense
+                  # tensor alive (B*T*T floats per entry)
 MASK_MAX_T = 256   # include/ggcn.h GGCN_MASK_MAX_T: largest graph the row-mask (one-launch layer) path takes
 MASKS_ONLY_MAX_T = 128   # from_dense: up to here the one-launch layer is the default consumer, the CSR arrays are made on demand
 
 
+def tensor_version(t):
+    """The autograd version counter of ``t``, or None for an inference tensor (``torch.inference_mode``): those
+    track no version, so nothing keyed on it -- the identity cache, the staleness check -- applies to them."""
+    try:
+        return None if t.is_inference() else t._version
+    except RuntimeError:
+        return None
+
+
 def cached_from_dense(adj, binary=None):
     """``BatchedCSR.from_dense`` with a small identity-keyed cache (see ``_RECENT``)."""
-    for ref, ver, want, csr in _RECENT:
-        if ref() is adj and ver == adj._version and want == binary:
+    ver = tensor_version(adj)
+    if ver is None:   # no version counter: an in-place edit could not be noticed, so nothing is cached
+        return BatchedCSR.from_dense(adj, binary=binary)
+    for ref, v, want, csr in _RECENT:
+        if ref() is adj and v == ver and want == binary:
             return csr
     csr = BatchedCSR.from_dense(adj, binary=binary)
-    _RECENT.insert(0, (weakref.ref(adj), adj._version, binary, csr))
+    _RECENT.insert(0, (weakref.ref(adj), ver, binary, csr))
     del _RECENT[_RECENT_MAX:]
     return csr
 
@@ -47,7 +61,7 @@ class BatchedCSR:
     kernel: all the fused layer needs); the CSR arrays are materialised on first access."""
 
     __slots__ = ("_rowptr", "_colidx", "_vals", "rowmask", "B", "T", "nnz", "is_binary",
-                 "_dense", "_dense_version", "_t", "_inv", "__weakref__")
+                 "_dense", "_dense_version", "_t", "_inv", "_graph_ops", "__weakref__")
 
     def __init__(self, rowptr, colidx, vals, B, T, nnz=None, rowmask=None):
         self._rowptr, self._colidx, self._vals, self.rowmask = rowptr, colidx, vals, rowmask
@@ -57,6 +71,21 @@ class BatchedCSR:
         self._dense_version = None
         self._t = None       # cached CSR of the transposed adjacency (backward pass)
         self._inv = None     # cached 1/(rowsum+1) per node
+        self._graph_ops = None   # cached ggcn_graph_operands blocks (T <= 32)
+
+    @property
+    def graph_ops(self):
+        """uint8 [B * GGCN_GRAPH_OPS_BYTES] or None: what the one-launch layer / block reads per graph of <= 32 nodes
+        (adjacency in MFMA operand order + reciprocal denominators), built from the row masks on first use."""
+        if self._graph_ops is None and self.rowmask is not None and self.T <= 32 and self.rowmask.is_cuda:
+            lib = _capi.load_library()
+            dev = self.rowmask.device
+            ops = torch.empty(lib.ggcn_graph_operands_bytes(self.B), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _capi.check(lib.ggcn_graph_operands(_capi.ptr(self.rowmask), self.B, self.T, _capi.ptr(ops),
+                                                    _capi.stream_of(dev)), "ggcn_graph_operands")
+            self._graph_ops = ops
+        return self._graph_ops
 
     @property
     def device(self):
@@ -85,9 +114,9 @@ class BatchedCSR:
         """The dense adjacency this CSR was built from, for the lazily built parts (CSR arrays, transposed CSR).
         It must not have been modified in place since: the row masks already in use would no longer match."""
         adj = self._dense
-        if adj is not None and adj._version != self._dense_version:
+        if adj is not None and self._dense_version is not None and tensor_version(adj) != self._dense_version:
             raise RuntimeError("the dense adjacency was modified in place after its BatchedCSR was built "
-                               "(version %d -> %d): build a new BatchedCSR" % (self._dense_version, adj._version))
+                               "(version %s -> %s): build a new BatchedCSR" % (self._dense_version, tensor_version(adj)))
         return adj
 
     def _materialize(self):
@@ -133,7 +162,7 @@ class BatchedCSR:
         flags = torch.empty(1, dtype=torch.int32, device=dev) if binary is None else None
         sb, sr, sc = adj.stride()
         out = cls(None, None, None, B, T)
-        out._dense, out._dense_version = adj, adj._version
+        out._dense, out._dense_version = adj, tensor_version(adj)
         if T <= MASKS_ONLY_MAX_T:
             out.rowmask = torch.empty(n * ((T + 31) // 32), dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):

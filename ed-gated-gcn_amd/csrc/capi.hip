@@ -61,23 +61,30 @@ int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
     return csr_rowmask(rowptr, colidx, B, T, rowmask, as_stream(stream));
 }
 
-int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask,
+size_t ggcn_graph_operands_bytes(int B) { return B > 0 ? (size_t)B * GGCN_GRAPH_OPS_BYTES : 0; }
+
+int ggcn_graph_operands(const uint32_t *rowmask, int B, int T, void *graph_ops, ggcn_stream_t stream)
+{
+    return graph_operands(rowmask, B, T, graph_ops, as_stream(stream));
+}
+
+int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops,
                      const float *bias, int B, int T, int K, int F, const float *store_gate,
                      const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
                      float *pool_a, float *pool_b, float *overlap_partial, const float *overlap_in,
                      float *overlap_out, int precision, ggcn_stream_t stream)
 {
-    return layer_fused(X, ldx, wpack, rowmask, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out,
+    return layer_fused(X, ldx, wpack, rowmask, graph_ops, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out,
                        ldo, pool_a, pool_b, overlap_partial, overlap_in, overlap_out, precision, as_stream(stream));
 }
 
-int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const uint32_t *rowmask,
+int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
                      const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
                      const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
                      float *x1, float *y1, float *pool_out, float *overlap_partial, int precision,
                      ggcn_stream_t stream)
 {
-    return block_fused(X, ldx, wpack1, wpack12, rowmask, bias1, bias_mid, bias2, B, T, K, F, gate1, gate2, gcn1, ld1,
+    return block_fused(X, ldx, wpack1, wpack12, graph_ops, bias1, bias_mid, bias2, B, T, K, F, gate1, gate2, gcn1, ld1,
                        x_out, ld2, x1, y1, pool_out, overlap_partial, precision, as_stream(stream));
 }
 

@@ -39,6 +39,7 @@
 // 23 % fewer W bytes through L2 for 16 VALU per stage: fused layer -2 %, plain linear -3 %.
 #pragma once
 #include "bf16x3_core.h"
+#include "lab_hooks.h"
 
 namespace ggcn {
 namespace mx8 {
@@ -107,6 +108,8 @@ __device__ __forceinline__ int q_lds_off(int row, int chunk)
 }
 
 #define GGCN_SB() __builtin_amdgcn_sched_barrier(0)
+// timing-only elimination ladder (lab_hooks.h: GGCN_LAB_OFF, 0 in the product build)
+#define GGCN_ON(bit) constexpr (!((GGCN_LAB_OFF) & (bit)))
 
 template <typename AT, bool AVEC, bool KFULL, bool ZROWS>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
@@ -276,31 +279,52 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     //                                        of the next block's fragments (one slot ahead of use)
     //   slots 4-7 (block i): 2 MX  MFMAs   | the fp16 B fragments of the next stage, LDS reads
     // The MX operand of B is loaded at the top of its stage (used from slot 4 on).
+    // ladder: operands the switched-off steps would have produced (dead code when GGCN_LAB_OFF == 0)
+    f16x8 lab_h[2];
+    i32x8 lab_q;
+    i32x8 lab_bm[RN];
+    if constexpr ((GGCN_LAB_OFF) != 0) {
+        read_h(0, 0, lab_h);
+        read_q(0, 0, lab_q);
+        load_bq(kstage(0), bq, sq);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const i32x4 w = wh8_of(b0[j], b1[j], sq[j]);
+            lab_bm[j] = i32x8{w[0], w[1], w[2], w[3], bq[j][0], bq[j][1], bq[j][2], bq[j][3]};
+        }
+    }
     auto stage = [&](int st, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         const int k_next1 = kstage(st + 1) * BK;
         const int ka = kstage(st + 2) * BK;
         f16x8 ah[2][2];
         i32x8 aq[2];
-        read_h(buf, 0, ah[0]);
-        load_bq(kstage(st), bq, sq);
+        if GGCN_ON(8) read_h(buf, 0, ah[0]); else { ah[0][0] = lab_h[0]; ah[0][1] = lab_h[1]; }
+        if GGCN_ON(16) load_bq(kstage(st), bq, sq);
         GGCN_SB();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i < 3) read_h(buf, i + 1, ah[(i + 1) & 1]);
-            else read_q(buf, 0, aq[0]);
+            if GGCN_ON(8) {
+                if (i < 3) read_h(buf, i + 1, ah[(i + 1) & 1]);
+                else read_q(buf, 0, aq[0]);
+            } else {
+                if (i < 3) { ah[(i + 1) & 1][0] = lab_h[0]; ah[(i + 1) & 1][1] = lab_h[1]; }
+                else aq[0] = lab_q;
+            }
             GGCN_SB();
             acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[0], acc[i][0], 0, 0, 0);
             GGCN_SB();
-            if (i < NP) split_pass(i, k_next1);
+            if GGCN_ON(2) { if (i < NP) split_pass(i, k_next1); }
             GGCN_SB();
             acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[1], acc[i][1], 0, 0, 0);
             GGCN_SB();
-            if (i < NP) write_pass(buf ^ 1, i);
+            if GGCN_ON(4) { if (i < NP) write_pass(buf ^ 1, i); }
+            else { _Pragma("unroll") for (int q = 0; q < NQ; ++q) asm volatile("" :: "v"(sp[q].h01), "v"(sp[q].h23), "v"(sp[q].l8), "v"(sp[q].h8)); }
             GGCN_SB();
             acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[0], acc[i][0], 0, 0, 0);
             GGCN_SB();
-            if (i < NP) load_a_pass(i, ka);
+            if GGCN_ON(1) { if (i < NP) load_a_pass(i, ka); }
+            else { if (i < NP) { _Pragma("unroll") for (int c = 0; c < EPT; ++c) asm volatile("" : "+v"(ra[i][c])); } }
             GGCN_SB();
             acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[1], acc[i][1], 0, 0, 0);
             GGCN_SB();
@@ -310,22 +334,27 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         i32x8 bm[RN];
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
-            const i32x4 w = wh8_of(b0[j], b1[j], sq[j]);
-            bm[j] = i32x8{w[0], w[1], w[2], w[3], bq[j][0], bq[j][1], bq[j][2], bq[j][3]};
+            if GGCN_ON(32) {
+                const i32x4 w = wh8_of(b0[j], b1[j], sq[j]);
+                bm[j] = i32x8{w[0], w[1], w[2], w[3], bq[j][0], bq[j][1], bq[j][2], bq[j][3]};
+            } else {
+                bm[j] = lab_bm[j];
+            }
         }
         GGCN_SB();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i < 3) read_q(buf, i + 1, aq[(i + 1) & 1]);
+            if GGCN_ON(8) { if (i < 3) read_q(buf, i + 1, aq[(i + 1) & 1]); }
+            else { if (i < 3) aq[(i + 1) & 1] = lab_q; }
             GGCN_SB();
-            acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[0], acc[i][0], 0, 0, 0, scale_a, 0, sq[0]);
+            acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[0], acc[i][0], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[0]);
             GGCN_SB();
-            if (i == 0) load_bf(kstage(st + 1), b0, b1);  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
+            if GGCN_ON(16) { if (i == 0) load_bf(kstage(st + 1), b0, b1); }  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
             GGCN_SB();
-            acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[1], acc[i][1], 0, 0, 0, scale_a, 0, sq[1]);
+            acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[1], acc[i][1], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[1]);
             GGCN_SB();
         }
-        __syncthreads();
+        if GGCN_ON(64) __syncthreads();
     };
     int st = 0;
     for (; st + 1 < stages; st += 2) {
@@ -336,6 +365,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     set_cvt_saturate(false);
 }
 #undef GGCN_SB
+#undef GGCN_ON
 
 }  // namespace mx8
 }  // namespace ggcn

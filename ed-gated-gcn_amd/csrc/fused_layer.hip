@@ -61,7 +61,8 @@ struct LayerPart {
 struct FusedArgs {
     const float *X;
     int64_t ldx;
-    const uint32_t *rowmask;
+    const uint32_t *rowmask;    // graphs of 33..256 nodes (layer_fused_wide_kernel)
+    const char *graph_ops;      // graphs of <= 32 nodes: ggcn_graph_operands blocks (layer_fused_kernel)
     const float *ov_in;         // partials an EARLIER launch wrote: block 0 reduces them to *ov_out first
     float *ov_out;
     int B, T, K, F;
@@ -122,6 +123,87 @@ __device__ __forceinline__ f32x16 adj_times(const bf16x8 (&af)[2], const f32x16 
     return y;
 }
 
+
+// ---- the epilogue's operands per graph (ggcn_graph_operands; GGCN_GRAPH_OPS_BYTES each) ------------------------------
+//   [0, 1024)    adjacency as the A operand of the aggregation MFMA, k-step 0: lane l (row = l & 31, h = l >> 5)
+//                -> 16 B at 16 l; 16-bit element j = 0xFFFF where adj[row][node 16s + 8(j>>2) + 4h + (j&3)] != 0
+//   [1024, 2048) the same for k-step 1
+//   [2048, 2176) 1 / (rowsum(adj) + 1) (gcn.py:35) in accumulator order: float [h][16], entry r = the value of row
+//                (r & 3) + 8 (r >> 2) + 4 h
+// One AND with the plane type's 1.0 pattern turns the 0xFFFF elements into an exact MFMA operand; nothing about a graph
+// is computed per column tile any more (the expansion of the row masks, the IEEE division and the 16 ds_bpermute per
+// graph were ~45 VALU + 16 LDS operations per graph and wavefront: a tenth of the epilogue's instructions).
+constexpr int kOpsBytes = GGCN_GRAPH_OPS_BYTES;
+static_assert(kOpsBytes == 2048 + 128, "layout above");
+
+__global__ __launch_bounds__(256) void graph_operands_kernel(const uint32_t *__restrict__ rowmask, int B, int T,
+                                                             char *__restrict__ ops)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= B) return;   // wavefront-uniform
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t m = r < T ? rowmask[(int64_t)g * T + r] : 0u;   // T <= 32: one word per node
+    char *blk = ops + (int64_t)g * kOpsBytes;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = 16 * s + 8 * (q >> 1) + 2 * (q & 1) + 4 * h;
+            const uint32_t two = (m >> b) & 3u;
+            w[q] = (two & 1u) * 0xFFFFu + (two >> 1) * 0xFFFF0000u;
+        }
+        *reinterpret_cast<uint4 *>(blk + s * 1024 + lane * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    // lane idx (0..31) writes entry [h' = idx >> 4][r' = idx & 15]
+    const int rr = lane & 15, hh = (lane >> 4) & 1;
+    const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+    const uint32_t mrow = __shfl(m, row);
+    if (lane < 32) reinterpret_cast<float *>(blk + 2048)[lane] = 1.0f / (float)(__popc(mrow) + 1);
+}
+
+// acc -> two fp16 planes (hi = RNE fp16(v), lo = fp16(v - hi): residual <= 2^-22 |v| + 2^-25, fp16 subnormals are kept
+// by the conversions and by the MFMA -- tools/probes/denorm_probe.hip) as B-operand fragments of the two k-steps:
+// 1.5 VALU instructions per value (v_cvt_pk_f16_f32 per pair, v_fma_mixlo/hi_f16 per value) against 3 for the bf16 pair
+typedef _Float16 f16x8e __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h(const f32x16 &acc, f16x8e (&frag)[2][2])
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    union { f16x8e v; uint32_t w[4]; } hi[2], lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v0 = acc[8 * s + 2 * q], v1 = acc[8 * s + 2 * q + 1];
+            const h2 p = __builtin_convertvector(f2{v0, v1}, h2);
+            uint32_t l;
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(p), "v"(v0));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(p), "v"(v1));
+            hi[s].w[q] = __builtin_bit_cast(uint32_t, p);
+            lo[s].w[q] = l;
+        }
+    frag[0][0] = hi[0].v; frag[0][1] = hi[1].v;
+    frag[1][0] = lo[0].v; frag[1][1] = lo[1].v;
+}
+
+// plane type of the aggregation MFMAs: bf16 pairs for bf16x3 (full fp32 range), fp16 pairs for f16mx8 (whose inputs
+// are fp16-ranged anyway; a hidden value beyond 65504 becomes inf - inf = NaN in the output, never a silent clamp)
+template <int SCH> struct AggPlane;
+template <> struct AggPlane<0> {
+    typedef bf16x8 frag;
+    static constexpr uint32_t kOne = 0x3F803F80u;
+    static __device__ __forceinline__ void split(const f32x16 &t, frag (&f)[2][2]) { split2(t, f); }
+    static __device__ __forceinline__ f32x16 mma(const frag &a, const frag &b, const f32x16 &c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct AggPlane<1> {
+    typedef f16x8e frag;
+    static constexpr uint32_t kOne = 0x3C003C00u;
+    static __device__ __forceinline__ void split(const f32x16 &t, frag (&f)[2][2]) { split2h(t, f); }
+    static __device__ __forceinline__ f32x16 mma(const frag &a, const frag &b, const f32x16 &c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
 // mean_b sum_f of the per-(graph, 64-column group) partials, in a fixed order (deterministic); one workgroup
 __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int n_part, int B, float *__restrict__ dst,
                                                 float *red)
@@ -136,13 +218,241 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
     __syncthreads();
 }
 
+
+// ---- LDS behind the main loop's buffers: what the epilogue reads, fetched BEFORE the main loop ----------------------
+// A global load issued inside the epilogue waits 1-2 us on a chip whose memory queues are full (measured: operand
+// blocks requested one graph ahead made the layer 10 % slower than expanding the masks in registers), so everything the
+// epilogue needs is copied to LDS at kernel start -- the 4 graphs of a workgroup are the same for its 4 wavefronts:
+//   [kEpiOps  ]  4 x GGCN_GRAPH_OPS_BYTES   operand blocks of graphs g0 .. g0+3
+//   [kEpiGate ]  3 x [4 graphs][256 columns] floats: store gate, pool gate a, pool gate b (1.0 where the gate is NULL)
+//   [kEpiBias ]  2 x [256 columns] floats: bias, mid bias (0 where NULL)
+constexpr int kEpiOps = kLdsBytes;
+constexpr int kEpiGate = kEpiOps + 4 * kOpsBytes;
+constexpr int kEpiBias = kEpiGate + 3 * 4 * BN * 4;
+constexpr int kEpiLdsBytes = kEpiBias + 2 * BN * 4 - kLdsBytes;   // 8704 + 12288 + 2048 = 23040
+static_assert(WM == 1, "one wavefront row: the workgroup's 4 graphs are every wavefront's 4 graphs");
+
+__device__ __forceinline__ void stage_epilogue_operands(const FusedArgs &a, const LayerPart &lp, int g0, int n_wgi, char *lds)
+{
+    const int tid = threadIdx.x, B = a.B, F = a.F;
+    // operand blocks: 544 pieces of 16 B
+    uint4 piece[3];
+    const int n_pieces = 4 * kOpsBytes / 16;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int idx = tid + it * kThreads;
+        const int idc = idx < n_pieces ? idx : 0;
+        const int gi = (idc * 16) / kOpsBytes;
+        // a graph past the batch reads graph g0's bytes instead (never used)
+        const int64_t off = (int64_t)g0 * kOpsBytes + (g0 + gi < B ? idc * 16 : idc * 16 - gi * kOpsBytes);
+        piece[it] = *reinterpret_cast<const uint4 *>(a.graph_ops + off);
+    }
+    // gates and biases of this workgroup's 256 columns
+    const int col = n_wgi * BN + tid;
+    const bool cok = col < F;
+    const float *dummy = a.X;
+    const float *gp[3] = {lp.store_gate, lp.pool_gate_a, lp.pool_gate_b};
+    float gv[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = gp[k] && cok && g0 + i < B;
+            const float v = (gp[k] ? gp[k] : dummy)[ok ? (int64_t)(g0 + i) * F + col : 0];
+            gv[k][i] = ok ? v : 1.0f;
+        }
+    const float vbias = (lp.bias ? lp.bias : dummy)[lp.bias && cok ? col : 0];
+    const float vmidb = (lp.mid ? lp.mid : dummy)[lp.mid && cok ? col : 0];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int idx = tid + it * kThreads;
+        if (idx < n_pieces) *reinterpret_cast<uint4 *>(lds + kEpiOps + idx * 16) = piece[it];
+    }
+    float *gl = reinterpret_cast<float *>(lds + kEpiGate);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gl[(k * 4 + i) * BN + tid] = gv[k][i];
+    float *bl = reinterpret_cast<float *>(lds + kEpiBias);
+    bl[tid] = lp.bias && cok ? vbias : 0.0f;
+    bl[BN + tid] = lp.mid && cok ? vmidb : 0.0f;
+    // visible to every wavefront after the main loop's first barrier
+}
+
+// ---- the epilogue of one wavefront: its 4 graphs x RN column tiles ------------------------------------------------
+// MID: the block's second layer through W12 (two aggregations with the `mid` bias in between); OUT: the [N,F] output is
+// stored.  Per graph: both column tiles are split, multiplied by the adjacency and finished side by side, so that one
+// tile's element-wise work issues under the other's MFMA chain.
+template <int SCH, bool FULLT, bool VST, bool MID, bool OUT>
+__device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp, f32x16 (&acc)[4][RN], int g0, int nt0,
+                                         int n_tiles_total, char *lds)
+{
+    using P = AggPlane<SCH>;
+    typedef typename P::frag frag;
+    const int B = a.B, T = a.T, F = a.F;
+    float *__restrict__ out = lp.out, *__restrict__ pool_a = lp.pool_a, *__restrict__ pool_b = lp.pool_b;
+    float *__restrict__ ov_partial = lp.ov_partial;
+    const int ldo = lp.ldo;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+
+    // operands staged in LDS before the main loop (stage_epilogue_operands): adjacency fragments, reciprocal denominators,
+    // gates, biases
+    const char *ops_lds = lds + kEpiOps;
+    const float *gate_lds = reinterpret_cast<const float *>(lds + kEpiGate);
+    const float *bias_lds = reinterpret_cast<const float *>(lds + kEpiBias);
+    const int wn = wave % WN;
+    float vb[RN], vmid[RN];
+    bool col_ok[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        col_ok[j] = (nt0 + j) * NT + c < F;
+        vb[j] = bias_lds[wn * (RN * NT) + j * NT + c];
+        vmid[j] = bias_lds[BN + wn * (RN * NT) + j * NT + c];
+    }
+    const int lane_off = 4 * h * ldo + c;  // this lane's element inside a (graph, column tile) block
+    // the A buffers are free after the main loop's last barrier: 8 KiB per wavefront = 32 rows x 64 columns
+    float *stage_lds = reinterpret_cast<float *>(lds) + wave * (32 * 64);
+    constexpr bool vst = VST && OUT;
+    constexpr bool direct_store = !VST && OUT;
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = g0 + i;
+        if (!FULLT && g >= B) break;  // workgroup-uniform
+        // adjacency fragments of graph g: the stored 0xFFFF elements become the plane type's 1.0
+        frag afv[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(ops_lds + i * kOpsBytes + s * 1024 + lane * 16);
+            union { frag v; uint32_t w[4]; } u;
+            u.w[0] = raw.x & P::kOne; u.w[1] = raw.y & P::kOne;
+            u.w[2] = raw.z & P::kOne; u.w[3] = raw.w & P::kOne;
+            afv[s] = u.v;
+        }
+        float4 rv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4 *>(ops_lds + i * kOpsBytes + 2048 + h * 64 + q * 16);
+        float vsg[RN], vga[RN], vgb[RN];
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const int at = i * BN + wn * (RN * NT) + j * NT + c;
+            vsg[j] = gate_lds[at];
+            vga[j] = gate_lds[4 * BN + at];
+            vgb[j] = gate_lds[8 * BN + at];
+        }
+        bool tile_ok[RN];
+#pragma unroll
+        for (int j = 0; j < RN; ++j) tile_ok[j] = nt0 + j < n_tiles_total;   // wavefront-uniform: column tile past F
+
+        // gcn.py:41 (layer 1 / the layer): agg = ADJ_g . hidden_g, small plane first; the column tiles' chains are
+        // issued one behind the other, so that a tile's split and element-wise work sit under the other's MFMAs
+        f32x16 y[RN];
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            frag hf[2][2];
+            P::split(acc[i][j], hf);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[j][r] = 0.0f;
+#pragma unroll
+            for (int p = 1; p >= 0; --p)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) y[j] = P::mma(afv[s], hf[p][s], y[j]);
+        }
+        float rinv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rinv[4 * q] = rv[q].x; rinv[4 * q + 1] = rv[q].y; rinv[4 * q + 2] = rv[q].z; rinv[4 * q + 3] = rv[q].w;
+        }
+        if constexpr (MID) {   // the block's second layer through W12 = W1.W2 (header): D.A.(X.W12) + c, then gcn.py:41 again
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                f32x16 u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[r] = y[j][r] * rinv[r] + vmid[j];
+                frag hf[2][2];
+                P::split(u, hf);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[j][r] = 0.0f;
+#pragma unroll
+                for (int p = 1; p >= 0; --p)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) y[j] = P::mma(afv[s], hf[p][s], y[j]);
+            }
+        }
+        float dot = 0.0f;  // this wavefront's share of sum_f x1[g,f] * y1[g,f] (bert_amir5.py:638)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            if (!tile_ok[j]) break;
+            const int gn = (nt0 + j) * NT + c;
+            // a gate is constant over the rows of a graph and rounding is monotonic, so
+            // max_t fl(y_t * g) == fl(g * max_t y_t) for g >= 0 (and g * min_t y_t for g < 0):
+            // track max and min of y once, apply both pool gates at the end (bert_amir5.py:635-640)
+            float vmax = -INFINITY, vmin = INFINITY;
+            float *tile = OUT ? out + ((int64_t)g * T) * ldo + (nt0 + j) * NT : nullptr;  // wave-uniform
+            const float sg = vsg[j];
+            const float bj = vb[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
+                const float v = y[j][r] * rinv[r] + bj;   // gcn.py:41,43
+                if constexpr (vst) {
+                    // staged for the 16-byte row stores below; columns of the rows with bit 2 set are
+                    // swapped between the two 32-column halves so that h = 0 / 1 hit different banks
+                    stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = v * sg;
+                }
+                if (FULLT || row0 + 4 * h < T) {
+                    if (direct_store && col_ok[j]) tile[lane_off + row0 * ldo] = v * sg;  // bert_amir5.py:626 / :639
+                    vmax = fmaxf(vmax, v);
+                    vmin = fminf(vmin, v);
+                }
+            }
+            // the other lane half's value: v_permlane32_swap (one VALU instruction; __shfl_xor(.., 32) is a
+            // ds_bpermute, an LDS round trip in front of the pooled stores).  Only lanes 0-31 use the result.
+            vmax = fmaxf(vmax, upper_half_to_lower(vmax));
+            vmin = fminf(vmin, upper_half_to_lower(vmin));
+            if (h == 0 && col_ok[j]) {
+                const float ga = vga[j], gb = vgb[j];
+                const float pa = ga * (ga >= 0.0f ? vmax : vmin), pb = gb * (gb >= 0.0f ? vmax : vmin);
+                if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
+                if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
+                dot = fmaf(pa, pb, dot);
+            }
+        }
+        if (ov_partial && nt0 < n_tiles_total) {  // fixed butterfly order; lanes with h = 1 hold 0
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
+            if (lane == 0) ov_partial[(int64_t)g * ((F + 63) / 64) + (nt0 >> 1)] = dot;
+        }
+        if constexpr (vst) {
+            // rows of 64 columns (both column tiles of this wavefront) leave as 16 B per lane: one
+            // instruction stores 4 rows x 256 contiguous bytes instead of 2 rows x 128 B
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int colq = (lane & 15) * 4;
+            const int gcol = nt0 * NT + colq;
+            float *gbase = out + ((int64_t)g * T) * ldo + gcol;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = 4 * it + (lane >> 4);
+                const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 64 + (colq ^ (32 * ((row >> 2) & 1)))]);
+                if ((FULLT || row < T) && gcol < F) *reinterpret_cast<float4 *>(gbase + row * ldo) = v4;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (i == 0) GGCN_TRACE(7);
+    }
+}
+
 // SCH: 0 = bf16x3 main loop, 1 = f16mx8 (f16mx8_core.h)
 // FULLT: T == 32 and B % 4 == 0 (every row of every tile is a real node): drops every guard.
 // VST: the [N,F] output leaves through LDS as 16-byte row stores (needs F, ldo multiples of 4 and a 16-byte aligned out)
 template <int SCH, bool AVEC, bool KFULL, bool FULLT, bool VST>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(const FusedArgs a)
 {
-    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes + GGCN_LAB_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes + kEpiLdsBytes + GGCN_LAB_LDS_PAD];
     const int B = a.B, T = a.T, K = a.K, F = a.F;
     // bert_amir5.py:638 for the launch BEFORE this one on the stream: block 0 adds the per-(graph,
     // 64-column group) partial dot products that launch left in ov_in, in a fixed order
@@ -169,12 +479,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
     // the part this workgroup's column tiles belong to (workgroup-uniform: scalar selects)
     const LayerPart &lp = a.part[second ? 1 : 0];
     const char *__restrict__ wpack = lp.wpack;
-    const float *__restrict__ bias = lp.bias, *__restrict__ mid = lp.mid;
-    const float *__restrict__ store_gate = lp.store_gate;
-    const float *__restrict__ pool_gate_a = lp.pool_gate_a, *__restrict__ pool_gate_b = lp.pool_gate_b;
-    float *__restrict__ out = lp.out, *__restrict__ pool_a = lp.pool_a, *__restrict__ pool_b = lp.pool_b;
-    float *__restrict__ ov_partial = lp.ov_partial;
-    const int ldo = lp.ldo;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -197,16 +501,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
         const int64_t node = avalid[i] ? (int64_t)g * T + r : 0;  // clamped, zeroed by the select
         arow[i] = a.X + node * a.ldx;
     }
-    // this lane's adjacency row (node lane&31) of each of the 4 graphs: in flight under the main loop
-    uint32_t mask[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g = g0 + i;
-        const bool ok = (g < B) && (FULLT || (lane & 31) < T);
-        const uint32_t m = a.rowmask[ok ? (int64_t)g * T + (lane & 31) : 0];
-        mask[i] = ok ? m : 0u;
-    }
 
+    stage_epilogue_operands(a, lp, g0, n_wgi, lds);   // g0 = gt0: one wavefront row
     f32x16 acc[4][RN];
     GGCN_TRACE(4);
     if constexpr (SCH == 0)
@@ -214,138 +510,27 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
     else
         mx8::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
     GGCN_TRACE(5);
-
-    const int c = lane & 31, h = lane >> 5;
-    // bias and the gates of the 4 graphs x 2 column tiles: all loads issued together, one latency.  The loads
-    // are unconditional (a NULL operand reads X[0] instead and is replaced by its neutral value where it is
-    // USED): a branch around each load makes hipcc wait for the loads inside the issuing block, in front of
-    // the first graph's adjacency MFMAs instead of behind them.
-    float vb[RN], vmid[RN], vsg[4][RN], vga[4][RN], vgb[4][RN];
-    bool col_ok[RN];
-    {
-        const float *dummy = a.X;
-        const float *pb = bias ? bias : dummy, *pm = mid ? mid : dummy;
-        const float *psg = store_gate ? store_gate : dummy, *pga = pool_gate_a ? pool_gate_a : dummy,
-                    *pgb = pool_gate_b ? pool_gate_b : dummy;
+    if constexpr (((GGCN_LAB_OFF) & 128) != 0) {   // ladder: no epilogue (the accumulators only have to stay live)
+        float s = 0.0f;
 #pragma unroll
-        for (int j = 0; j < RN; ++j) {
-            const int gn = (nt0 + j) * NT + c;
-            col_ok[j] = gn < F;
-            const int gnc = col_ok[j] ? gn : 0;
-            vb[j] = pb[bias ? gnc : 0];
-            vmid[j] = pm[mid ? gnc : 0];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int64_t at = (int64_t)(g0 + i < B ? g0 + i : 0) * F + gnc;
-                vsg[i][j] = psg[store_gate ? at : 0];
-                vga[i][j] = pga[pool_gate_a ? at : 0];
-                vgb[i][j] = pgb[pool_gate_b ? at : 0];
-            }
-        }
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 123.456f && lp.pool_a) lp.pool_a[tid] = s;
+        return;
     }
-    const int lane_off = 4 * h * ldo + c;  // this lane's element inside a (graph, column tile) block
-    // the A buffers are free after the main loop's last barrier: 8 KiB per wavefront = 32 rows x 64 columns
-    float *stage_lds = reinterpret_cast<float *>(lds) + wave * (32 * 64);
-    const int perm_base = 16 * h;          // ds_bpermute byte address of lane 4h (+ 4*row0 per register)
-    // The graph loop exists twice, with and without the [N,F] output: `out` is workgroup-uniform (NULL for the
-    // W1 tiles of the block), and a test of it inside the element loop puts a scalar branch around every one of a
-    // tile's 16 staging stores -- 16 basic blocks per tile that nothing can be scheduled across.
-    auto graphs = [&](auto has_out) {
-    constexpr bool vst = VST && decltype(has_out)::value;
-    constexpr bool direct_store = !VST && decltype(has_out)::value;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g = g0 + i;
-        if (g >= B) break;  // workgroup-uniform
-        // ---- adjacency fragments of graph g from this lane's row mask: element j of k-step s is
-        // node 16s + 8(j>>2) + 4h + (j&3); two neighbouring elements = two neighbouring mask bits ----
-        bf16x8 afv[2];
-        expand_mask(mask[i] >> (4 * h), afv);
-        // 1 / (rowsum(adj) + 1) of node lane&31 (gcn.py:35): one IEEE division per node, then the
-        // value of row row0 + 4h is fetched per accumulator register through the LDS crossbar
-        const float inv = 1.0f / (float)(__popc(mask[i]) + 1);
-        float rinv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row0 = (r & 3) + 8 * (r >> 2);
-            rinv[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_base + 4 * row0, __float_as_int(inv)));
-        }
-
-        float dot = 0.0f;  // this wavefront's share of sum_f x1[g,f] * y1[g,f] (bert_amir5.py:638)
-#pragma unroll
-        for (int j = 0; j < RN; ++j) {
-            if (nt0 + j >= n_tiles_total) break;  // wavefront-uniform: column tile past F
-            const int gn = (nt0 + j) * NT + c;
-
-            f32x16 y = adj_times(afv, acc[i][j]);                                     // gcn.py:41 (layer 1 / the layer)
-            if (mid) {  // workgroup-uniform: the block's second layer through W12 = W1.W2 (header)
-                f32x16 u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) u[r] = y[r] * rinv[r] + vmid[j];          // D.A.(X.W12) + c (mid != NULL here)
-                y = adj_times(afv, u);                                                 // gcn.py:41 of layer 2
-            }
-
-            // a gate is constant over the rows of a graph and rounding is monotonic, so
-            // max_t fl(y_t * g) == fl(g * max_t y_t) for g >= 0 (and g * min_t y_t for g < 0):
-            // track max and min of y once, apply both pool gates at the end (bert_amir5.py:635-640)
-            float vmax = -INFINITY, vmin = INFINITY;
-            float *tile = out ? out + ((int64_t)g * T) * ldo + (nt0 + j) * NT : nullptr;  // wave-uniform
-            const float sg = store_gate ? vsg[i][j] : 1.0f;
-            const float bj = bias ? vb[j] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
-                const float v = y[r] * rinv[r] + bj;      // gcn.py:41,43
-                if (vst) {
-                    // staged for the 16-byte row stores below; columns of the rows with bit 2 set are
-                    // swapped between the two 32-column halves so that h = 0 / 1 hit different banks
-                    stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = v * sg;
-                }
-                if (FULLT || row0 + 4 * h < T) {
-                    if (direct_store && col_ok[j]) tile[lane_off + row0 * ldo] = v * sg;  // bert_amir5.py:626 / :639
-                    vmax = fmaxf(vmax, v);
-                    vmin = fminf(vmin, v);
-                }
-            }
-            // the other lane half's value: v_permlane32_swap (one VALU instruction; __shfl_xor(.., 32) is a
-            // ds_bpermute, an LDS round trip in front of the pooled stores).  Only lanes 0-31 use the result.
-            vmax = fmaxf(vmax, upper_half_to_lower(vmax));
-            vmin = fminf(vmin, upper_half_to_lower(vmin));
-            if (h == 0 && col_ok[j]) {
-                const float ga = pool_gate_a ? vga[i][j] : 1.0f, gb = pool_gate_b ? vgb[i][j] : 1.0f;
-                const float pa = ga * (ga >= 0.0f ? vmax : vmin), pb = gb * (gb >= 0.0f ? vmax : vmin);
-                if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
-                if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
-                dot = fmaf(pa, pb, dot);
-            }
-        }
-        if (ov_partial && nt0 < n_tiles_total) {  // fixed butterfly order; lanes with h = 1 hold 0
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
-            if (lane == 0) ov_partial[(int64_t)g * ((F + 63) / 64) + (nt0 >> 1)] = dot;
-        }
-        if (vst) {
-            // rows of 64 columns (both column tiles of this wavefront) leave as 16 B per lane: one
-            // instruction stores 4 rows x 256 contiguous bytes instead of 2 rows x 128 B
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int colq = (lane & 15) * 4;
-            const int gcol = nt0 * NT + colq;
-            float *gbase = out + ((int64_t)g * T) * ldo + gcol;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = 4 * it + (lane >> 4);
-                const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 64 + (colq ^ (32 * ((row >> 2) & 1)))]);
-                if ((FULLT || row < T) && gcol < F) *reinterpret_cast<float4 *>(gbase + row * ldo) = v4;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (i == 0) GGCN_TRACE(7);
+    // `mid` and `out` are workgroup-uniform run-time facts (the W1 / W12 tiles of the block): four straight-line
+    // epilogues instead of scalar branches inside one -- a branch per tile ends the basic block, and nothing (the
+    // other column tile's split, the next graph's loads) can then be scheduled into the shadow of a tile's MFMA chain
+    if (lp.mid) {
+        if (lp.out) epilogue<SCH, FULLT, VST, true, true>(a, lp, acc, g0, nt0, n_tiles_total, lds);
+        else epilogue<SCH, FULLT, VST, true, false>(a, lp, acc, g0, nt0, n_tiles_total, lds);
+    } else {
+        if (lp.out) epilogue<SCH, FULLT, VST, false, true>(a, lp, acc, g0, nt0, n_tiles_total, lds);
+        else epilogue<SCH, FULLT, VST, false, false>(a, lp, acc, g0, nt0, n_tiles_total, lds);
     }
-    };
-    if (out) graphs(std::true_type{});
-    else graphs(std::false_type{});
     GGCN_TRACE(6);
 }
 
@@ -629,7 +814,11 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
 {
     if (precision != GGCN_PREC_BF16X3 && precision != GGCN_PREC_F16MX8)
         return fail(GGCN_EUNSUPPORTED, "%s: precision %d (use bf16x3 or f16mx8)", who, precision);
-    if (!a.X || !a.rowmask) return fail(GGCN_EINVAL, "%s: null input pointer", who);
+    if (!a.X) return fail(GGCN_EINVAL, "%s: null input pointer", who);
+    if (a.T > 32 ? !a.rowmask : !a.graph_ops)
+        return fail(GGCN_EINVAL, "%s: graphs of %d nodes need %s", who, a.T,
+                    a.T > 32 ? "the row masks" : "the per-graph operand blocks of ggcn_graph_operands");
+    if (a.T <= 32 && !aligned16(a.graph_ops)) return fail(GGCN_EINVAL, "%s: graph_ops must be 16-byte aligned", who);
     if (a.B <= 0 || a.T <= 0 || a.K <= 0 || a.F <= 0)
         return fail(GGCN_EINVAL, "%s: B=%d T=%d K=%d F=%d must be positive", who, a.B, a.T, a.K, a.F);
     if (a.T > GGCN_MASK_MAX_T)
@@ -717,8 +906,19 @@ int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint
     return check_launch("ggcn_csr_rowmask");
 }
 
-int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const float *bias,
-                int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
+int graph_operands(const uint32_t *rowmask, int B, int T, void *ops, hipStream_t st)
+{
+    if (!rowmask || !ops) return fail(GGCN_EINVAL, "ggcn_graph_operands: null pointer");
+    if (B <= 0 || T <= 0) return fail(GGCN_EINVAL, "ggcn_graph_operands: B=%d T=%d must be positive", B, T);
+    if (T > 32) return fail(GGCN_EUNSUPPORTED, "ggcn_graph_operands: T=%d > 32 (larger graphs are applied from their row masks)", T);
+    if (!aligned16(ops)) return fail(GGCN_EINVAL, "ggcn_graph_operands: ops must be 16-byte aligned");
+    hipLaunchKernelGGL(graph_operands_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, rowmask, B, T,
+                       static_cast<char *>(ops));
+    return check_launch("ggcn_graph_operands");
+}
+
+int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops,
+                const float *bias, int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,
                 float *overlap_partial, const float *overlap_in, float *overlap_out, int precision, hipStream_t st)
 {
@@ -726,14 +926,15 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
         return fail(GGCN_EINVAL, "ggcn_layer_fused: overlap_in and overlap_out go together");
     if (out && ldo > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused: ldo too large");
     FusedArgs a = {};
-    a.X = X; a.ldx = ldx; a.rowmask = rowmask; a.ov_in = overlap_in; a.ov_out = overlap_out;
+    a.X = X; a.ldx = ldx; a.rowmask = rowmask; a.graph_ops = static_cast<const char *>(graph_ops);
+    a.ov_in = overlap_in; a.ov_out = overlap_out;
     a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = 1;
     a.part[0] = LayerPart{static_cast<const char *>(wpack), bias, nullptr, store_gate, pool_gate_a, pool_gate_b,
                           out, pool_a, pool_b, overlap_partial, (int)ldo};
     return launch_fused("ggcn_layer_fused", a, precision, st);
 }
 
-int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const uint32_t *rowmask,
+int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
                 const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
                 const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
                 float *x1, float *y1, float *pool_out, float *overlap_partial, int precision, hipStream_t st)
@@ -744,7 +945,7 @@ int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpa
     if ((gcn1 && ld1 > (int64_t)INT32_MAX) || (x_out && ld2 > (int64_t)INT32_MAX))
         return fail(GGCN_EUNSUPPORTED, "ggcn_block_fused: leading dimension too large");
     FusedArgs a = {};
-    a.X = X; a.ldx = ldx; a.rowmask = rowmask;
+    a.X = X; a.ldx = ldx; a.graph_ops = static_cast<const char *>(graph_ops);
     a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = 2;
     // bert_amir5.py:626-636: gcn1 (ungated; optional here), x1 = max_t gcn1*gate1, y1 = max_t gcn1*gate2
     a.part[0] = LayerPart{static_cast<const char *>(wpack1), bias1, nullptr, nullptr, gate1, gate2,

@@ -7,6 +7,19 @@
 #define GGCN_LAB_LDS_PAD 0
 #endif
 
+// timing-only probes of the correction MFMA's operand format (cbsz = blgp: 0 fp8 e4m3, 2 fp6 e2m3, 3 bf6 e3m2, 4 fp4);
+// anything but 0 reads the fp8 operands as another format: wrong results, right instruction timing
+#ifndef GGCN_LAB_MXFMT
+#define GGCN_LAB_MXFMT 0
+#endif
+
+// timing-only elimination ladder of the f16mx8 main loop (bit set = that step is switched off; wrong results):
+// 1 X global loads, 2 split VALU, 4 LDS plane writes, 8 LDS fragment reads, 16 W loads, 32 wh8 converts, 64 barrier,
+// 128 epilogue (fused_layer.hip)
+#ifndef GGCN_LAB_OFF
+#define GGCN_LAB_OFF 0
+#endif
+
 #ifdef GGCN_LAB_TRACE
 // timeline probe: per workgroup {block, HW_ID, XCC_ID, t_start, t_loop_begin, t_loop_end, t_end} in 10 ns ticks
 __device__ unsigned long long ggcn_trace_buf[8192 * 8];

@@ -18,7 +18,7 @@ also applies the gate and the max over tokens.
 import torch
 
 from . import _capi
-from .csr import BatchedCSR
+from .csr import BatchedCSR, tensor_version
 
 
 def gate_overlap(x1, y1):
@@ -44,7 +44,7 @@ def _block_operands(gc1, gc2, lib, st):
     linear (a k-ordered fp32 FMA chain): they are parameters folded once per weight update, not activations."""
     w1, w2, b1 = gc1.weight, gc2.weight, gc1.bias
     prec = _capi.PREC[gc1.precision]
-    key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version, None if b1 is None else (b1.data_ptr(), b1._version),
+    key = (w1.data_ptr(), tensor_version(w1), w2.data_ptr(), tensor_version(w2), None if b1 is None else (b1.data_ptr(), tensor_version(b1)),
            w1.device, prec)
     cached = getattr(gc2, "_block_ops", None)
     if cached is None or cached[0] != key:
@@ -117,7 +117,7 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
             b1 = None if gc1.bias is None else gc1.bias.detach()
             b2 = None if gc2.bias is None else gc2.bias.detach()
             _capi.check(lib.ggcn_block_fused(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack1), _capi.ptr(pack12),
-                                             _capi.ptr(csr.rowmask), _capi.ptr(b1), _capi.ptr(mid), _capi.ptr(b2),
+                                             _capi.ptr(csr.graph_ops), _capi.ptr(b1), _capi.ptr(mid), _capi.ptr(b2),
                                              B, T, K, F, _capi.ptr(gate1), _capi.ptr(gate2), _capi.ptr(gcn1), F,
                                              _capi.ptr(xo), F, _capi.ptr(x1), _capi.ptr(y1), _capi.ptr(out),
                                              _capi.ptr(part), _capi.PREC[gc1.precision], st), "ggcn_block_fused")

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _capi
-from .csr import BatchedCSR, cached_from_dense
+from .csr import BatchedCSR, cached_from_dense, tensor_version
 
 
 def _require_gpu_f32(name, t, allow_half=False):
@@ -163,7 +163,7 @@ class GraphConvolution(nn.Module):
         w = self.weight
         # the transposed image only serves the backward's dX linear, which is always bf16x3
         prec = _capi.PREC[self.precision if (self.precision in _capi.PACKED and not transposed) else "bf16x3"]
-        key = (w.data_ptr(), w._version, w.device, prec)
+        key = (w.data_ptr(), tensor_version(w), w.device, prec)
         slot = 1 if transposed else 0
         if self._pack is None:
             self._pack, self._pack_key = [None, None], [None, None]
@@ -336,7 +336,7 @@ class GraphConvolution(nn.Module):
             if use_fused:
                 pack = self._packed_weight(lib, st)
                 _capi.check(lib.ggcn_layer_fused(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack),
-                                                 _capi.ptr(csr.rowmask), _capi.ptr(bias), B, T,
+                                                 _capi.ptr(csr.rowmask), _capi.ptr(csr.graph_ops), _capi.ptr(bias), B, T,
                                                  self.in_features, F, _capi.ptr(store_gate),
                                                  _capi.ptr(pool_gate_a), _capi.ptr(pool_gate_b), _capi.ptr(out),
                                                  F, _capi.ptr(pa), _capi.ptr(pb), _capi.ptr(overlap_partial),

@@ -11,12 +11,13 @@ reference's PyTorch ops for these ~0.1 GFLOP pieces, so ``train.py:115-121`` tra
 import torch
 
 from . import _capi
+from .csr import tensor_version
 
 
 def _transposed(linear, lib, st):
     """[in,out] copy of an nn.Linear weight, rebuilt when the weight changes."""
     w = linear.weight
-    key = (w.data_ptr(), w._version, w.device)
+    key = (w.data_ptr(), tensor_version(w), w.device)
     cached = getattr(linear, "_ggcn_wt", None)
     if cached is None or cached[0] != key:
         wc = w.detach()

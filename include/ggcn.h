@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 6
+#define GGCN_ABI_VERSION 7
 #define GGCN_MASK_MAX_T 256   /* largest graph the row-mask (one-launch) path takes */
 
 typedef void *ggcn_stream_t;
@@ -110,6 +110,15 @@ int ggcn_rowmask_from_dense(const void *adj, int adj_dtype, int B, int T,
 int ggcn_csr_transpose(const int32_t *rowptr, const int32_t *colidx, const float *vals, int B, int T,
                        int32_t *rowptr_t, int32_t *colidx_t, float *vals_t, void *workspace,
                        ggcn_stream_t stream);
+
+/* Per-graph operand blocks of the one-launch layer / block for graphs of <= 32 nodes, from the row masks
+ * (one word per node): GGCN_GRAPH_OPS_BYTES per graph = the 0/1 adjacency laid out as the A operand of the
+ * aggregation MFMA (2 x 1 KiB) + 1/(rowsum(adj)+1) of its 32 rows in accumulator order (models/gcn.py:35).
+ * Built once per adjacency (it replaces, per column tile and wavefront, the expansion of the masks, 32 IEEE
+ * divisions and 16 cross-lane moves per graph).  graph_ops: ggcn_graph_operands_bytes(B) bytes, 16-byte aligned. */
+#define GGCN_GRAPH_OPS_BYTES 2176
+size_t ggcn_graph_operands_bytes(int B);
+int ggcn_graph_operands(const uint32_t *rowmask, int B, int T, void *graph_ops, ggcn_stream_t stream);
 
 /* Row masks from an existing batched CSR (T <= GGCN_MASK_MAX_T). */
 int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
@@ -227,8 +236,9 @@ int ggcn_layer_fused_h(const void *X, int64_t ldx, const void *wpack,
  * `hidden`: the linear's accumulator tile (one graph x 32 features) is multiplied by
  * the graph's 0/1 adjacency with a second MFMA, then divided, biased, gated, pooled and
  * stored.  Same outputs and argument meaning as ggcn_linear(GGCN_PREC_BF16X3) followed by
- * ggcn_aggregate; X is [B*T, K], wpack from ggcn_weight_pack(K, F, precision), rowmask
- * uint32[B*T][ceil(T/32)]; precision is GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8.  T <= 32: one 32x32
+ * ggcn_aggregate; X is [B*T, K], wpack from ggcn_weight_pack(K, F, precision); T <= 32 reads graph_ops
+ * (ggcn_graph_operands; rowmask may be NULL), T > 32 reads rowmask uint32[B*T][ceil(T/32)] (graph_ops may be
+ * NULL); precision is GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8.  T <= 32: one 32x32
  * accumulator tile is one graph.  32 < T <= 128: a graph takes a 64- or 128-row slot of a wavefront's tile and
  * its adjacency is applied as ceil(T/32)^2 blocks of 32x32 bits (LitBank: ORI_ML = 100, constant.py:227).
  * The gate-diversity regulariser (models/bert_amir5.py:638) can ride along instead of taking
@@ -236,7 +246,8 @@ int ggcn_layer_fused_h(const void *X, int64_t ldx, const void *wpack,
  * and 64-column group, sum_f pool_a[g,f]*pool_b[g,f] of THIS launch (layer 1: x1.y1); overlap_in /
  * overlap_out (both or neither) make this launch first reduce the partials an EARLIER launch on the
  * same stream wrote (same B, F) to *overlap_out = mean_b sum_f, in a fixed order (deterministic). */
-int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask,
+int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack,
+                     const uint32_t *rowmask, const void *graph_ops,
                      const float *bias, int B, int T, int K, int F,
                      const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
                      float *out, int64_t ldo, float *pool_a, float *pool_b,
@@ -259,7 +270,7 @@ int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint3
  * it with ggcn_overlap_reduce.  Same flop count as two ggcn_layer_fused launches; X is read once and the
  * 4.N.F-byte write + read of gcn1 disappears.  Training keeps the two-launch path (autograd needs gcn1). */
 int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12,
-                     const uint32_t *rowmask, const float *bias1, const float *bias_mid, const float *bias2,
+                     const void *graph_ops, const float *bias1, const float *bias_mid, const float *bias2,
                      int B, int T, int K, int F, const float *gate1, const float *gate2,
                      float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
                      float *x1, float *y1, float *pool_out, float *overlap_partial,

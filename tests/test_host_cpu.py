@@ -57,9 +57,11 @@ def test_bad_arguments_return_codes_not_crashes():
     assert rc == 1
     rc = lib.ggcn_csr_from_dense(None, 0, 1, 4, 16, 4, 1, None, None, None, 16, None, None, None, None)
     assert rc == 1
-    rc = lib.ggcn_layer_fused(None, 8, None, None, None, 1, 4, 8, 8, None, None, None, None, 8, None, None, None, None,
+    rc = lib.ggcn_layer_fused(None, 8, None, None, None, None, 1, 4, 8, 8, None, None, None, None, 8, None, None, None, None,
                               None, 0, None)
     assert rc == 1
+    rc = lib.ggcn_graph_operands(None, 1, 4, None, None)
+    assert rc == 1 and lib.ggcn_graph_operands_bytes(3) == 3 * 2176
     rc = lib.ggcn_csr_rowmask(None, None, 1, 4, None, None)
     assert rc == 1
 

@@ -72,9 +72,14 @@ def time_variants(what, names):
         base = n.split("@")[0]  # "name@mx8" times the f16mx8 precision of that build
         path = os.path.join(LAB, "libggcn_%s.so" % base) if base != "main" else pkg.lib_path()
         lib = ctypes.CDLL(path)
+        lib.ggcn_abi_version.restype = ctypes.c_int
+        new_abi = lib.ggcn_abi_version() >= 7      # 7: graph_ops argument (ggcn_graph_operands blocks)
         for fn, (res, args) in _capi.PROTOTYPES.items():
             if hasattr(lib, fn):
+                if fn == "ggcn_layer_fused" and not new_abi:
+                    args = args[:4] + args[5:]
                 getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
+        lib._new_abi = new_abi
         prec = 2 if n.endswith("@mx8") else 0
         pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H, prec), dtype=torch.uint8, device=dev)
         assert lib.ggcn_weight_pack(_capi.ptr(w), H, H, H, prec, 0, _capi.ptr(pack), None) == 0
@@ -84,6 +89,8 @@ def time_variants(what, names):
 
     def run(n):
         lib, pack, prec = libs[n]
+        masks = (p(csr.rowmask), p(csr.graph_ops)) if lib._new_abi else (p(csr.rowmask),)
+        gops = p(csr.graph_ops) if lib._new_abi else p(csr.rowmask)
         if what == "linear":
             rc = lib.ggcn_linear(p(x), H, p(w), H, p(pack), p(y), H, N, H, H, prec, st)
         elif what == "linear_pp":     # lab_pp.hip: ping-pong form of the f16mx8 linear (falls back to the plain linear)
@@ -100,18 +107,18 @@ def time_variants(what, names):
             rc = lib.ggcn_aggregate(p(x), H, p(csr.rowptr), p(csr.colidx), None, p(b), B, T, H, None, p(g1), p(g2),
                                     p(out), H, p(pa), p(pb), st)
         elif what == "fused_noout":   # pooled outputs only: no [N,F] store at all
-            rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
+            rc = lib.ggcn_layer_fused(p(x), H, p(pack), *masks, p(b), B, T, H, H, None, p(g1), p(g2),
                                       None, H, p(pa), p(pb), None, None, None, prec, st)
         elif what == "fused2":        # the block's two layers back to back: layer 2 reads what layer 1 wrote
-            rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
+            rc = lib.ggcn_layer_fused(p(x), H, p(pack), *masks, p(b), B, T, H, H, None, p(g1), p(g2),
                                       p(out), H, p(pa), p(pb), None, None, None, prec, st)
-            rc = rc or lib.ggcn_layer_fused(p(out), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, p(g2), p(g2), None,
+            rc = rc or lib.ggcn_layer_fused(p(out), H, p(pack), *masks, p(b), B, T, H, H, p(g2), p(g2), None,
                                             p(y), H, p(pa), None, None, None, None, prec, st)
         elif what == "blockfused":    # the whole gated block as one launch (timing: W12 := the same image)
-            rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack), p(csr.rowmask), p(b), p(b), p(b), B, T, H, H, p(g1), p(g2),
+            rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack), gops, p(b), p(b), p(b), B, T, H, H, p(g1), p(g2),
                                       None, H, p(out), H, p(pa), p(pb), p(pc), p(part), prec, st)
         elif what == "fused":
-            rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2),
+            rc = lib.ggcn_layer_fused(p(x), H, p(pack), *masks, p(b), B, T, H, H, None, p(g1), p(g2),
                                       p(out), H, p(pa), p(pb), None, None, None, prec, st)
         else:
             raise SystemExit("unknown target " + what)

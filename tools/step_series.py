@@ -23,7 +23,7 @@ pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H, 2), dtype=torch.uint8, devic
 assert lib.ggcn_weight_pack(p(w), H, H, H, 2, 0, p(pack), None) == 0
 st = _capi.stream_of(dev)
 def run():
-    assert lib.ggcn_block_fused(p(x), H, p(pack), p(pack), p(csr.rowmask), p(b), p(b), p(b), B, T, H, H, p(g1), p(g2), None, H, p(out), H,
+    assert lib.ggcn_block_fused(p(x), H, p(pack), p(pack), p(csr.graph_ops), p(b), p(b), p(b), B, T, H, H, p(g1), p(g2), None, H, p(out), H,
                                 p(pa), p(pb), p(pc), p(part), 2, st) == 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 for _ in range(300): run()

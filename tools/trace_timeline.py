@@ -36,11 +36,11 @@ assert lib.ggcn_weight_pack(p(w.t().contiguous()), H, H, H, prec, 0, p(pack12), 
 part = torch.empty(B, 12, device=dev)
 def run():
     if BLOCK:
-        rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack12), p(csr.rowmask), p(b), p(b), p(b), B, T, H, H, p(g1), p(g2),
+        rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack12), p(csr.graph_ops), p(b), p(b), p(b), B, T, H, H, p(g1), p(g2),
                                   None, H, p(out), H, p(pa), p(pb), p(pa), p(part), prec, None)
         assert rc == 0
         return
-    rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(b), B, T, H, H, None, p(g1), p(g2), None if NOOUT else p(out), H,
+    rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(csr.graph_ops), p(b), B, T, H, H, None, p(g1), p(g2), None if NOOUT else p(out), H,
                               p(pa), p(pb), None, None, None, prec, None)
     assert rc == 0
 for _ in range(int(os.environ.get('TRACE_WARMUP', '300'))):   # the chip needs ~0.1 s of load to settle
