@@ -1049,6 +1049,32 @@ def test_two_rank_sharded_block_same_device(pkg, dev):
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
 
 
+def test_bench_self_launches_its_ranks_and_the_gathered_logits_match_the_unsharded_batch(pkg, dev):
+    """`python bench.py --gpus 2` typed as is (what a driver without torch.distributed.run would run): the parent
+    touches no GPU, starts two rank processes and relays rank 0's JSON line.  The ranks run bench.py's OWN N > 1 step
+    loop -- hipGraph replay of the sharded block, the logits head, one asynchronous all-gather per step -- here over
+    gloo with both ranks on cuda:0 (one-GPU box; on the 8-GPU node the backend is RCCL), and `--check-gather` compares
+    the last gathered logits with the unsharded 96-graph batch: graphs are independent, so bit for bit."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
+           "--graphs", "96", "--steps", "6", "--warmup", "2", "--precondition", "4", "--no-alt", "--no-cpu-baseline",
+           "--check-gather"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["steps"] == 6
+    assert r["rccl"]["world_size_seen"] == 2 and r["rccl"]["backend"] == "gloo"
+    assert r["rccl"]["gather_bytes_per_rank"] == max(r["config"]["graphs_per_gpu"]) * 34 * 4
+    assert sum(r["config"]["graphs_per_gpu"]) == 96
+    assert r["config"]["hipgraph_replay"] is True, r["config"]["capture_note"]
+    assert r["gather_check"]["bitwise_equal"] is True and r["gather_check"]["rows"] == 96, r["gather_check"]
+    assert r["value"] > 0 and "roofline" in r
+
+
 # ---------------------------------------------------------------- the drop-in forward(text, adj): syncs, cache, defaults
 def test_dropin_forward_is_sync_free_and_shares_the_conversion(pkg, dev):
     """models/gcn.py:30-45 has no device synchronisation; neither has forward(text, dense adj) here when the
