@@ -60,8 +60,8 @@ PROTOTYPES = {
 }
 
 ABI_VERSION = 7
-PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2, "f16": 3}
-PACKED = ("bf16x3", "f16mx8", "f16")  # precisions whose linear reads a ggcn_weight_pack image ("f16": half features only)
+PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2, "f16": 3, "f16mx6": 4}
+PACKED = ("bf16x3", "f16mx8", "f16", "f16mx6")  # precisions whose linear reads a ggcn_weight_pack image ("f16": half features only)
 FLAG_WEIGHTED = 1
 
 

@@ -36,6 +36,7 @@
 // Graphs with T < 32 occupy a 32-row slot (rows >= T read as zeros, are never stored and never
 // pooled); T > 32 or weighted adjacency -> the unfused path (linear + aggregate.hip).
 #include "f16mx8_core.h"
+#include "f16mx6_core.h"
 #include "lab_hooks.h"
 
 namespace ggcn {
@@ -204,6 +205,8 @@ template <> struct AggPlane<1> {
     static __device__ __forceinline__ f32x16 mma(const frag &a, const frag &b, const f32x16 &c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
+template <> struct AggPlane<2> : AggPlane<1> {};   // f16mx6: fp16 planes as well
+
 // mean_b sum_f of the per-(graph, 64-column group) partials, in a fixed order (deterministic); one workgroup
 __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int n_part, int B, float *__restrict__ dst,
                                                 float *red)
@@ -226,15 +229,22 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
 //   [kEpiOps  ]  4 x GGCN_GRAPH_OPS_BYTES   operand blocks of graphs g0 .. g0+3
 //   [kEpiGate ]  3 x [4 graphs][256 columns] floats: store gate, pool gate a, pool gate b (1.0 where the gate is NULL)
 //   [kEpiBias ]  2 x [256 columns] floats: bias, mid bias (0 where NULL)
-constexpr int kEpiOps = kLdsBytes;
-constexpr int kEpiGate = kEpiOps + 4 * kOpsBytes;
-constexpr int kEpiBias = kEpiGate + 3 * 4 * BN * 4;
-constexpr int kEpiLdsBytes = kEpiBias + 2 * BN * 4 - kLdsBytes;   // 8704 + 12288 + 2048 = 23040
+template <int BASE>
+struct EpiLds {   // byte offsets of the staged operands; the store staging of the epilogue is always [0, 32 KiB)
+    static constexpr int kOps = BASE;
+    static constexpr int kGate = kOps + 4 * kOpsBytes;
+    static constexpr int kBias = kGate + 3 * 4 * BN * 4;
+    static constexpr int kEnd = kBias + 2 * BN * 4;
+};
+constexpr int kEpiLdsBytes = EpiLds<0>::kEnd;   // 8704 + 12288 + 2048 = 23040
 static_assert(WM == 1, "one wavefront row: the workgroup's 4 graphs are every wavefront's 4 graphs");
+static_assert(mx6::kRaw >= 32768 && EpiLds<mx6::kRaw>::kEnd <= mx6::kLdsBytes6, "f16mx6: the operands go where the RAW stages were");
 
-__device__ __forceinline__ void stage_epilogue_operands(const FusedArgs &a, const LayerPart &lp, int g0, int n_wgi, char *lds)
+template <int BASE>
+__device__ __forceinline__ void stage_epilogue_operands(const FusedArgs &a, const LayerPart &lp, int g0, int n_wgi, char *lds, int tid)
 {
-    const int tid = threadIdx.x, B = a.B, F = a.F;
+    constexpr int kEpiOps = EpiLds<BASE>::kOps, kEpiGate = EpiLds<BASE>::kGate, kEpiBias = EpiLds<BASE>::kBias;
+    const int B = a.B, F = a.F;
     // operand blocks: 544 pieces of 16 B
     uint4 piece[3];
     const int n_pieces = 4 * kOpsBytes / 16;
@@ -283,18 +293,19 @@ __device__ __forceinline__ void stage_epilogue_operands(const FusedArgs &a, cons
 // MID: the block's second layer through W12 (two aggregations with the `mid` bias in between); OUT: the [N,F] output is
 // stored.  Per graph: both column tiles are split, multiplied by the adjacency and finished side by side, so that one
 // tile's element-wise work issues under the other's MFMA chain.
-template <int SCH, bool FULLT, bool VST, bool MID, bool OUT>
+template <int SCH, bool FULLT, bool VST, bool MID, bool OUT, int BASE = kLdsBytes>
 __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp, f32x16 (&acc)[4][RN], int g0, int nt0,
-                                         int n_tiles_total, char *lds)
+                                         int n_tiles_total, char *lds, int tid)
 {
+    constexpr int kEpiOps = EpiLds<BASE>::kOps, kEpiGate = EpiLds<BASE>::kGate, kEpiBias = EpiLds<BASE>::kBias;
     using P = AggPlane<SCH>;
     typedef typename P::frag frag;
     const int B = a.B, T = a.T, F = a.F;
     float *__restrict__ out = lp.out, *__restrict__ pool_a = lp.pool_a, *__restrict__ pool_b = lp.pool_b;
     float *__restrict__ ov_partial = lp.ov_partial;
     const int ldo = lp.ldo;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
 
     // operands staged in LDS before the main loop (stage_epilogue_operands): adjacency fragments, reciprocal denominators,
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
         arow[i] = a.X + node * a.ldx;
     }
 
-    stage_epilogue_operands(a, lp, g0, n_wgi, lds);   // g0 = gt0: one wavefront row
+    stage_epilogue_operands<kLdsBytes>(a, lp, g0, n_wgi, lds, tid);   // g0 = gt0: one wavefront row
     f32x16 acc[4][RN];
     GGCN_TRACE(4);
     if constexpr (SCH == 0)
@@ -525,13 +536,86 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
     // epilogues instead of scalar branches inside one -- a branch per tile ends the basic block, and nothing (the
     // other column tile's split, the next graph's loads) can then be scheduled into the shadow of a tile's MFMA chain
     if (lp.mid) {
-        if (lp.out) epilogue<SCH, FULLT, VST, true, true>(a, lp, acc, g0, nt0, n_tiles_total, lds);
-        else epilogue<SCH, FULLT, VST, true, false>(a, lp, acc, g0, nt0, n_tiles_total, lds);
+        if (lp.out) epilogue<SCH, FULLT, VST, true, true>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid);
+        else epilogue<SCH, FULLT, VST, true, false>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid);
     } else {
-        if (lp.out) epilogue<SCH, FULLT, VST, false, true>(a, lp, acc, g0, nt0, n_tiles_total, lds);
-        else epilogue<SCH, FULLT, VST, false, false>(a, lp, acc, g0, nt0, n_tiles_total, lds);
+        if (lp.out) epilogue<SCH, FULLT, VST, false, true>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid);
+        else epilogue<SCH, FULLT, VST, false, false>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid);
     }
     GGCN_TRACE(6);
+}
+
+
+// ---- the same layer / block with the f16mx6 main loop (f16mx6_core.h): 96 instead of 128 matrix-pipe cycles per 32^3 block ----
+// Fast path only: K % 32 == 0, 16-byte aligned rows of X (LDS-DMA moves 16 bytes per lane).  LDS: PLANE + RAW =
+// 64 KiB, two workgroups per CU; the epilogue's operands are fetched into the RAW stages once the main loop has released them.
+template <bool FULLT, bool VST>
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused6_kernel(const FusedArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char lds[mx6::kLdsBytes6];
+    const int B = a.B, T = a.T, K = a.K, F = a.F;
+    if (a.ov_in && blockIdx.x == 0) reduce_partials(a.ov_in, B * ((F + 63) / 64), B, a.ov_out, reinterpret_cast<float *>(lds));
+    int g_tile, n_wgi;
+    bool second = false;
+    if (a.n_parts == 1) {
+        if (!tile_of_block(blockIdx.x, a.g_tiles, a.n_wg, g_tile, n_wgi)) return;
+    } else {   // four XCDs take the W1 tiles, four the W12 tiles (layer_fused_kernel)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        second = xcd >= 4;
+        g_tile = (slot / a.n_wg) * 4 + (xcd & 3);
+        n_wgi = slot % a.n_wg;
+        if (g_tile >= a.g_tiles) return;
+    }
+    const LayerPart &lp = a.part[second ? 1 : 0];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g0 = g_tile * 4;
+    const int n_tiles_total = (F + NT - 1) / NT;
+    const int nt0 = n_wgi * (BN / NT) + wave * RN;
+
+    // DMA sources: piece j of this wavefront = tile rows 32 wave + 8 j + (lane >> 3), chunk (lane & 7) ^ swizzle(row)
+    const float *xtile = a.X + (int64_t)g0 * T * a.ldx;   // workgroup-uniform; 128 rows x ldx floats stay below 4 GiB (launcher)
+    uint32_t aoff[2];   // pieces 2, 3 = pieces 0, 1 sixteen rows further (same swizzle): a uniform stride in the FULLT build
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 32 * wave + 8 * j + (lane >> 3);
+        const int g = g0 + (row >> 5), r = row & 31;
+        const bool ok = (g < B) && (FULLT || r < T);
+        const int node = ok ? (row >> 5) * T + r : 0;       // inside the tile; clamped: the split zeroes such a block
+        aoff[j] = (uint32_t)(((int64_t)node * a.ldx + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4);
+    }
+    const int urow = 32 * wave + (lane >> 1);   // the row whose half block this lane splits
+    const bool uvalid = (g0 + (urow >> 5) < B) && (FULLT || (urow & 31) < T);
+
+    f32x16 acc[4][RN];
+    const int64_t rows_left = (int64_t)B * T - (int64_t)g0 * T;
+    const uint32_t xtile_bytes = (uint32_t)(((rows_left < 128 ? rows_left : 128) - 1) * a.ldx * 4 + (int64_t)K * 4);
+    mx6::mainloop<!FULLT>(xtile, xtile_bytes, aoff, (uint32_t)(16 * a.ldx * 4), uvalid, lp.wpack, K, a.k_steps / 2, nt0, n_tiles_total, lds, acc);
+    if constexpr (((GGCN_LAB_OFF) & 128) != 0) {   // ladder: no epilogue
+        float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 123.456f && lp.pool_a) lp.pool_a[tid] = sacc;
+        return;
+    }
+    // everything the epilogue derives from the thread id is derived AFTER the loop (the asm makes the id opaque): hipcc
+    // otherwise computes those per-lane offsets and pointers up front and keeps ~25 registers alive across a loop that
+    // has none to spare
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    stage_epilogue_operands<mx6::kRaw>(a, lp, g0, n_wgi, lds, tid_e);   // the RAW stages are free: the loop ended on a barrier
+    __syncthreads();
+    if (lp.mid) {
+        if (lp.out) epilogue<2, FULLT, VST, true, true, mx6::kRaw>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid_e);
+        else epilogue<2, FULLT, VST, true, false, mx6::kRaw>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid_e);
+    } else {
+        if (lp.out) epilogue<2, FULLT, VST, false, true, mx6::kRaw>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid_e);
+        else epilogue<2, FULLT, VST, false, false, mx6::kRaw>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid_e);
+    }
 }
 
 // ---- graphs of 33..256 nodes (LitBank: ORI_ML = 100, constant.py:227; ACE cased: ORI_ML = 231, constant.py:267)
@@ -812,8 +896,8 @@ __global__ __launch_bounds__(256) void rowmask_kernel(const int32_t *__restrict_
 // shared argument checks + launch of layer_fused_kernel for 1 or 2 parts
 int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
 {
-    if (precision != GGCN_PREC_BF16X3 && precision != GGCN_PREC_F16MX8)
-        return fail(GGCN_EUNSUPPORTED, "%s: precision %d (use bf16x3 or f16mx8)", who, precision);
+    if (precision != GGCN_PREC_BF16X3 && precision != GGCN_PREC_F16MX8 && precision != GGCN_PREC_F16MX6)
+        return fail(GGCN_EUNSUPPORTED, "%s: precision %d (use bf16x3, f16mx8 or f16mx6)", who, precision);
     if (!a.X) return fail(GGCN_EINVAL, "%s: null input pointer", who);
     if (a.T > 32 ? !a.rowmask : !a.graph_ops)
         return fail(GGCN_EINVAL, "%s: graphs of %d nodes need %s", who, a.T,
@@ -845,6 +929,8 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
     const bool kfull = (a.K % BK == 0);
     a.k_steps = round_up(a.K, BK) / KSTEP;
     a.n_wg = (a.F + BN - 1) / BN;
+    if (a.T > 32 && precision == GGCN_PREC_F16MX6)
+        return fail(GGCN_EUNSUPPORTED, "%s: f16mx6 takes graphs of <= 32 nodes (T=%d); use f16mx8", who, a.T);
     if (a.T > 32) {   // 64-, 128- or 256-row graph slots: layer_fused_wide_kernel
         const int sb = a.T <= 64 ? 2 : a.T <= 128 ? 4 : 8;
         const int gpt = sb == 2 ? 2 : 1;   // graphs per workgroup
@@ -872,6 +958,18 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: batch too large", who);
     a.g_tiles = (int)g_tiles;
     const bool fullt = (a.T == 32) && (a.B % (4 * WM) == 0);
+    if (precision == GGCN_PREC_F16MX6) {
+        if (!(avec && kfull) || (int64_t)128 * a.ldx * 4 >= ((int64_t)1 << 31))
+            return fail(GGCN_EUNSUPPORTED, "%s: f16mx6 needs K %% 32 == 0 and 16-byte aligned rows of X (K=%d ldx=%lld); use f16mx8",
+                        who, a.K, (long long)a.ldx);
+#define GGCN_LAUNCH6(FT, VS) hipLaunchKernelGGL((layer_fused6_kernel<FT, VS>), dim3((unsigned)grid), dim3(kThreads), 0, st, a)
+        if (fullt && vst) GGCN_LAUNCH6(true, true);
+        else if (fullt) GGCN_LAUNCH6(true, false);
+        else if (vst) GGCN_LAUNCH6(false, true);
+        else GGCN_LAUNCH6(false, false);
+#undef GGCN_LAUNCH6
+        return check_launch(who);
+    }
 #define GGCN_LAUNCH(SC, AV, KF, FT, VS) \
     hipLaunchKernelGGL((layer_fused_kernel<SC, AV, KF, FT, VS>), dim3((unsigned)grid), dim3(kThreads), 0, st, a)
 #define GGCN_PICK(SC)                                                                 \

@@ -15,6 +15,7 @@
 // loop is shared with fused_layer.hip).  This file adds the weight packers of both schemes and the
 // store epilogue (16-byte row stores through LDS for aligned fp32 output).
 #include "f16_core.h"
+#include "f16mx6_core.h"
 
 namespace ggcn {
 namespace {
@@ -122,6 +123,58 @@ __global__ __launch_bounds__(64) void weight_pack_mx8_kernel(const float *__rest
     // E8M0 (value = 2^(byte-127)): byte 0 = the scale of this lane's block for the MFMA (lane c: block 0,
     // lane c + 32: block 1), byte 1 = the scale of block 0 for the in-loop fp16 -> fp8 conversion
     *reinterpret_cast<int *>(base + 3072 + lane * 4) = ((127 - s0) << 8) | (127 - (h ? s1 : s0));
+}
+
+// ---- W -> f16mx6 image (f16mx6_core.h): per (32-column tile, 32-deep stage) [f16 frag k-step 0][k-step 1]
+// [64 lanes x {fp6 block 24 B, E8M0 scale dword, pad}]: lane (c, 0) holds fp6(wh / th) of column c's 32 k, lane (c, 1)
+// fp6(wl / tl); field f <-> k = f (the order the A side's converts produce); th, tl: the power of two that
+// puts the block's largest magnitude in (3.75, 7.5].  The hardware's own converter rounds (RNE, saturating).
+template <bool TR>
+__global__ __launch_bounds__(64) void weight_pack_mx6_kernel(const float *__restrict__ W, int64_t ldw, int K, int F,
+                                                            int stages, char *__restrict__ pack)
+{
+    const int n_tile = blockIdx.x, st = blockIdx.y, lane = threadIdx.x;
+    const int c = lane & 31, h = lane >> 5;
+    const int n = n_tile * NT + c;
+    char *base = pack + ((int64_t)n_tile * stages + st) * mx6::STAGE_PACK_BYTES;
+    auto wat = [&](int k) -> float {
+        return (k < K && n < F) ? (TR ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n]) : 0.0f;
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {   // fp16 fragments: k-step s, lane (c, h): k = 32 st + 16 s + 8 h + j
+        mx8::f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)wat(32 * st + 16 * s2 + 8 * h + j);
+        *reinterpret_cast<mx8::f16x8 *>(base + s2 * 1024 + lane * 16) = v;
+    }
+    float v[32], m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const float w = wat(32 * st + k);
+        const float wh = (float)(_Float16)w;
+        v[k] = h ? w - wh : wh;
+        m = fmaxf(m, fabsf(v[k]));
+    }
+    int te = 0;
+    if (m > 0.0f) {
+        int e;
+        const float f = frexpf(m, &e);          // m = f * 2^e, f in [0.5, 1)
+        te = f * 8.0f <= 7.5f ? e - 3 : e - 2;   // m / 2^te in (3.75, 7.5]
+        te = te < -126 ? -126 : (te > 127 ? 127 : te);
+    }
+    // v_cvt_scalef32_2xpk16_fp6_f32: field 2i <- a[i], field 2i + 1 <- b[i] (tools/probes/fp6_cvt_probe.hip)
+    typedef float f32x16v __attribute__((ext_vector_type(16)));
+    f32x16v a, b;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a[i] = ldexpf(v[2 * i], -te); b[i] = ldexpf(v[2 * i + 1], -te); }
+    mx6::u32x6 q;
+    const float one = 1.0f;
+    asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=v"(q) : "v"(a), "v"(b), "v"(one));
+    uint32_t *dst = reinterpret_cast<uint32_t *>(base + 2048 + lane * 32);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dst[i] = q[i];
+    dst[6] = (uint32_t)(127 + te);
+    dst[7] = 0u;
 }
 
 __device__ __forceinline__ void store_elem(float *p, float v) { *p = v; }
@@ -319,6 +372,7 @@ size_t weight_pack_bytes(int K, int F, int precision)
     const size_t stages = (size_t)bx3::round_up(K, bx3::BK) / bx3::BK;  // whole 32-deep stages
     const size_t n_tiles = (size_t)bx3::round_up(F, bx3::NT) / bx3::NT;
     if (precision == GGCN_PREC_F16MX8 || precision == GGCN_PREC_F16) return n_tiles * stages * mx8::STAGE_PACK_BYTES;
+    if (precision == GGCN_PREC_F16MX6) return n_tiles * stages * mx6::STAGE_PACK_BYTES;
     return n_tiles * stages * 2 * 2 * bx3::FRAG_BYTES;
 }
 
@@ -340,6 +394,16 @@ int weight_pack(const float *W, int64_t ldw, int K, int F, int precision, bool t
             hipLaunchKernelGGL(weight_pack_mx8_kernel<false>, grid, dim3(64), 0, st, W, ldw, K, F, k_steps / 2,
                                static_cast<char *>(wpack));
         return check_launch("ggcn_weight_pack(f16mx8)");
+    }
+    if (precision == GGCN_PREC_F16MX6) {
+        const dim3 grid((unsigned)n_tiles, (unsigned)(k_steps / 2));
+        if (transposed)
+            hipLaunchKernelGGL(weight_pack_mx6_kernel<true>, grid, dim3(64), 0, st, W, ldw, K, F, k_steps / 2,
+                               static_cast<char *>(wpack));
+        else
+            hipLaunchKernelGGL(weight_pack_mx6_kernel<false>, grid, dim3(64), 0, st, W, ldw, K, F, k_steps / 2,
+                               static_cast<char *>(wpack));
+        return check_launch("ggcn_weight_pack(f16mx6)");
     }
     if (precision != GGCN_PREC_BF16X3) return fail(GGCN_EINVAL, "ggcn_weight_pack: precision %d has no packed image", precision);
     if (transposed)

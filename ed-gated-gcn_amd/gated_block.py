@@ -34,7 +34,7 @@ def gate_overlap(x1, y1):
     return xy
 
 
-def _block_operands(gc1, gc2, lib, st):
+def _block_operands(gc1, gc2, lib, st, precision=None):
     """Operands of the one-launch block (``ggcn_block_fused``), rebuilt only when a parameter changes:
 
     * packed ``W1`` (gc1's own image), packed ``W12 = W1 . W2`` and ``mid = W2^T . b1``.
@@ -43,7 +43,8 @@ def _block_operands(gc1, gc2, lib, st):
     so ``gc2(gc1(x)) = D.A.(D.A.(x.W12) + mid) + b2``.  W12 and mid come from the library's exact-fp32 MFMA
     linear (a k-ordered fp32 FMA chain): they are parameters folded once per weight update, not activations."""
     w1, w2, b1 = gc1.weight, gc2.weight, gc1.bias
-    prec = _capi.PREC[gc1.precision]
+    precision = precision or gc1.precision
+    prec = _capi.PREC[precision]
     key = (w1.data_ptr(), tensor_version(w1), w2.data_ptr(), tensor_version(w2), None if b1 is None else (b1.data_ptr(), tensor_version(b1)),
            w1.device, prec)
     cached = getattr(gc2, "_block_ops", None)
@@ -63,7 +64,7 @@ def _block_operands(gc1, gc2, lib, st):
         _capi.check(lib.ggcn_weight_pack(_capi.ptr(w12), F2, K, F2, prec, 0, _capi.ptr(pack12), st), "ggcn_weight_pack(W12)")
         cached = (key, pack12, mid)
         gc2._block_ops = cached
-    return gc1._packed_weight(lib, st), cached[1], cached[2]
+    return gc1._packed_weight(lib, st, precision=precision), cached[1], cached[2]
 
 
 def takes_block_path(x, csr, gc1, gc2):
@@ -106,7 +107,8 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
                 raise RuntimeError("%s must be a contiguous float32 [B,F]=[%d,%d] GPU tensor" % (name, B, F))
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
-            pack1, pack12, mid = _block_operands(gc1, gc2, lib, st)
+            kprec = gc1.kernel_precision(x2d, csr)   # "f16mx6" where the fp6 kernel takes the shape, else "f16mx8"
+            pack1, pack12, mid = _block_operands(gc1, gc2, lib, st, precision=kprec)
             gcn1 = torch.empty(B * T, F, dtype=torch.float32, device=dev) if want_gcn1 else None
             xo = torch.empty(B * T, F, dtype=torch.float32, device=dev)
             x1 = torch.empty(B, F, dtype=torch.float32, device=dev)
@@ -120,7 +122,7 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
                                              _capi.ptr(csr.graph_ops), _capi.ptr(b1), _capi.ptr(mid), _capi.ptr(b2),
                                              B, T, K, F, _capi.ptr(gate1), _capi.ptr(gate2), _capi.ptr(gcn1), F,
                                              _capi.ptr(xo), F, _capi.ptr(x1), _capi.ptr(y1), _capi.ptr(out),
-                                             _capi.ptr(part), _capi.PREC[gc1.precision], st), "ggcn_block_fused")
+                                             _capi.ptr(part), _capi.PREC[kprec], st), "ggcn_block_fused")
             _capi.check(lib.ggcn_overlap_reduce(_capi.ptr(part), B, F, _capi.ptr(xy), st), "ggcn_overlap_reduce")
         return {"gcn1": None if gcn1 is None else gcn1.view(B, T, F), "x1": x1, "y1": y1, "xy": xy,
                 "x": xo.view(B, T, F), "out": out}

@@ -158,16 +158,20 @@ class GraphConvolution(nn.Module):
             self.in_features, self.out_features, self.bias is not None, self.precision)
 
     # -- weight image for the split-precision linears, rebuilt only when the weight changes ----------
-    def _packed_weight(self, lib, stream, transposed=False):
-        """MFMA-order image of W (forward) or W^T (backward's dX), rebuilt when W or the precision changes."""
+    def _packed_weight(self, lib, stream, transposed=False, precision=None):
+        """MFMA-order image of W (forward) or W^T (backward's dX) for `precision` (default: the layer's), rebuilt when W
+        changes; one image per precision is kept ("f16mx6" layers also need the "f16mx8" image for the shapes the
+        fp6 kernel does not take)."""
         w = self.weight
         # the transposed image only serves the backward's dX linear, which is always bf16x3
-        prec = _capi.PREC[self.precision if (self.precision in _capi.PACKED and not transposed) else "bf16x3"]
-        key = (w.data_ptr(), tensor_version(w), w.device, prec)
-        slot = 1 if transposed else 0
-        if self._pack is None:
-            self._pack, self._pack_key = [None, None], [None, None]
-        if self._pack[slot] is None or self._pack_key[slot] != key:
+        name = precision or self.precision
+        name = name if (name in _capi.PACKED and not transposed) else "bf16x3"
+        prec = _capi.PREC[name]
+        key = (w.data_ptr(), tensor_version(w), w.device)
+        slot = (name, bool(transposed))
+        if not isinstance(self._pack, dict):
+            self._pack, self._pack_key = {}, {}
+        if self._pack.get(slot) is None or self._pack_key.get(slot) != key:
             K, F = (self.out_features, self.in_features) if transposed else (self.in_features, self.out_features)
             pack = torch.empty(lib.ggcn_weight_pack_bytes(K, F, prec), dtype=torch.uint8, device=w.device)
             wc = w.detach()
@@ -177,6 +181,16 @@ class GraphConvolution(nn.Module):
                                              _capi.ptr(pack), stream), "ggcn_weight_pack")
             self._pack[slot], self._pack_key[slot] = pack, key
         return self._pack[slot]
+
+    def kernel_precision(self, x2d=None, csr=None):
+        """The arithmetic a launch really uses: "f16mx6" is taken by the one-launch layer / block for graphs of <= 32
+        nodes with K % 32 == 0 and 16-byte aligned fp32 rows; every other shape of such a layer runs "f16mx8" (the same
+        scheme with fp8 corrections: same accuracy class, its own weight image)."""
+        if self.precision != "f16mx6":
+            return self.precision
+        ok = (csr is not None and csr.T <= 32 and x2d is not None and x2d.dtype == torch.float32
+              and self.in_features % 32 == 0 and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0 and self.fused)
+        return "f16mx6" if ok else "f16mx8"
 
     def _as_csr(self, adj, text):
         if isinstance(adj, BatchedCSR):
@@ -209,7 +223,7 @@ class GraphConvolution(nn.Module):
         if self.weight.device != text.device:
             raise RuntimeError("weight is on %s but text is on %s" % (self.weight.device, text.device))
         if self.precision not in _capi.PREC:
-            raise RuntimeError("unknown precision %r (use 'bf16x3', 'f16mx8', 'fp32', or 'f16' for float16 features)"
+            raise RuntimeError("unknown precision %r (use 'bf16x3', 'f16mx8', 'f16mx6', 'fp32', or 'f16' for float16 features)"
                                % (self.precision,))
 
     def validate_range(self, text=None):
@@ -244,20 +258,21 @@ class GraphConvolution(nn.Module):
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
             y = torch.empty(x2d.shape[0], self.out_features, dtype=x2d.dtype, device=dev)
+            kprec = self.kernel_precision()   # "f16mx6" has no stand-alone linear: f16mx8
             if x2d.dtype == torch.float16:
-                pack = self._packed_weight(lib, st)  # noqa
+                pack = self._packed_weight(lib, st, precision=kprec)  # noqa
                 _capi.check(lib.ggcn_linear_h(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack), _capi.ptr(y),
                                               y.stride(0), x2d.shape[0], self.in_features, self.out_features,
-                                              _capi.PREC[self.precision], st),
+                                              _capi.PREC[kprec], st),
                             "ggcn_linear_h")
                 return y
             w = self.weight.detach()
             if not w.is_contiguous():
                 w = w.contiguous()
-            pack = self._packed_weight(lib, st) if self.precision in _capi.PACKED else None
+            pack = self._packed_weight(lib, st, precision=kprec) if kprec in _capi.PACKED else None
             _capi.check(lib.ggcn_linear(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(w), w.stride(0),
                                         _capi.ptr(pack), _capi.ptr(y), y.stride(0), x2d.shape[0],
-                                        self.in_features, self.out_features, _capi.PREC[self.precision], st),
+                                        self.in_features, self.out_features, _capi.PREC[kprec], st),
                         "ggcn_linear")
         return y
 
@@ -334,7 +349,8 @@ class GraphConvolution(nn.Module):
             pb = torch.empty(B, F, dtype=torch.float32, device=dev) if want_pool_b else None
             bias = None if self.bias is None else self.bias.detach()
             if use_fused:
-                pack = self._packed_weight(lib, st)
+                kprec = self.kernel_precision(x2d, csr)
+                pack = self._packed_weight(lib, st, precision=kprec)
                 _capi.check(lib.ggcn_layer_fused(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack),
                                                  _capi.ptr(csr.rowmask), _capi.ptr(csr.graph_ops), _capi.ptr(bias), B, T,
                                                  self.in_features, F, _capi.ptr(store_gate),
@@ -342,7 +358,7 @@ class GraphConvolution(nn.Module):
                                                  F, _capi.ptr(pa), _capi.ptr(pb), _capi.ptr(overlap_partial),
                                                  _capi.ptr(overlap_reduce[0]) if overlap_reduce else None,
                                                  _capi.ptr(overlap_reduce[1]) if overlap_reduce else None,
-                                                 _capi.PREC[self.precision], st),
+                                                 _capi.PREC[kprec], st),
                             "ggcn_layer_fused")
                 return (None if out is None else out.view(B, T, F)), pa, pb
             if use_long:   # long fp16 graphs (BASELINE configs[3]): linear + aggregation in one launch, hidden stays in LDS

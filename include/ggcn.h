@@ -72,9 +72,15 @@ enum ggcn_precision {
                               terms in ONE block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4):
                               2/3 of bf16x3's matrix-core time, |err| ~ 2^-15 |x||w| per product.
                               Needs |x|, |w| < 65504 (fp16 range; larger values saturate to inf) */
-    GGCN_PREC_F16 = 3      /* HALF-PRECISION FEATURES ONLY (ggcn_linear_h): plain fp16 MFMA on the fp16 image of W
+    GGCN_PREC_F16 = 3,     /* HALF-PRECISION FEATURES ONLY (ggcn_linear_h): plain fp16 MFMA on the fp16 image of W
                               (the fp16 fragments of the GGCN_PREC_F16MX8 pack), fp32 accumulate; |err| ~ 2^-12 |x||w|
                               per product -- below the rounding of the fp16 output it feeds */
+    GGCN_PREC_F16MX6 = 4   /* the F16MX8 scheme with the correction products in fp6 (e2m3): gfx950 runs the block-scaled
+                              MFMA twice as fast when both operands are 6-bit, so a product costs 3/4 of F16MX8's
+                              matrix-core time.  e2m3 spans 6 binades, so both operands carry TRUE per-(row or column,
+                              32 k) power-of-two scales (the activations' are computed in the kernel); |err| as F16MX8
+                              (+10 %).  Same range rule.  Taken by ggcn_layer_fused / ggcn_block_fused for graphs of
+                              <= 32 nodes with K % 32 == 0 and 16-byte aligned rows; its own ggcn_weight_pack image */
 };
 
 int ggcn_abi_version(void);

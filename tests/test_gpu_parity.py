@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import csr_ref, ref_dense  # noqa: E402  (tests may use the oracle)
 
-TOL = {"fp32": 2e-5, "bf16x3": 1e-4, "f16mx8": 1e-4}
+TOL = {"fp32": 2e-5, "bf16x3": 1e-4, "f16mx8": 1e-4, "f16mx6": 1e-4}
 
 
 @pytest.fixture(scope="module")
@@ -35,12 +35,12 @@ def pkg():
 
 
 # (precision, fused): the one-launch layer kernel exists for the two split-precision linears
-MODES = [("fp32", False), ("bf16x3", False), ("bf16x3", True), ("f16mx8", False), ("f16mx8", True)]
-MODE_IDS = ["fp32", "bf16x3-unfused", "bf16x3-fused", "f16mx8-unfused", "f16mx8-fused"]
+MODES = [("fp32", False), ("bf16x3", False), ("bf16x3", True), ("f16mx8", False), ("f16mx8", True), ("f16mx6", True)]
+MODE_IDS = ["fp32", "bf16x3-unfused", "bf16x3-fused", "f16mx8-unfused", "f16mx8-fused", "f16mx6-fused"]
 # block-level tests add the whole block as ONE launch (ggcn_block_fused: W1.W2 folded, gcn1 optional);
 # "fused" there means one launch per layer
-BLOCK_MODES = MODES + [("bf16x3", "block"), ("f16mx8", "block")]
-BLOCK_IDS = MODE_IDS + ["bf16x3-block", "f16mx8-block"]
+BLOCK_MODES = MODES + [("bf16x3", "block"), ("f16mx8", "block"), ("f16mx6", "block")]
+BLOCK_IDS = MODE_IDS + ["bf16x3-block", "f16mx8-block", "f16mx6-block"]
 
 
 def _block(pkg, x, adj, g1, g2, gc1, gc2, fused, want_gcn1=True):

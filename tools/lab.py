@@ -80,7 +80,7 @@ def time_variants(what, names):
                     args = args[:4] + args[5:]
                 getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
         lib._new_abi = new_abi
-        prec = 2 if n.endswith("@mx8") else 0
+        prec = 4 if n.endswith("@mx6") else 2 if n.endswith("@mx8") else 0
         pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H, prec), dtype=torch.uint8, device=dev)
         assert lib.ggcn_weight_pack(_capi.ptr(w), H, H, H, prec, 0, _capi.ptr(pack), None) == 0
         libs[n] = (lib, pack, prec)

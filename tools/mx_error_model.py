@@ -72,14 +72,20 @@ def run(M=1024, K=768, F=768, seed=0, xscale=1.0):
             xh_q = (q(xb(x.astype(np.float64)) / s_x) * s_x).reshape(M, K)
             s_l = block_scale(xb(xl), fmt, 2)
             xl_q = (q(xb(xl) / s_l) * s_l).reshape(M, K)
-        elif a_mode == "half":     # scale per 16-k half block pair shared... (same as block here)
-            raise SystemExit
+        elif a_mode in ("exp2_11", "exp2_12", "exp1_11"):   # what the kernel can afford: scale from the EXPONENT of the block
+            # maximum (2^(E-2): the maximum lands in [4, 8) and saturates above 7.5; or 2^(E-1): [2, 4)), xl scale = that * 2^-11 / 2^-12
+            m = np.abs(xb(x.astype(np.float64))).max(axis=2, keepdims=True)
+            E = np.floor(np.log2(np.maximum(m, 1e-30)))
+            s_x = np.exp2(E - (2 if a_mode.startswith("exp2") else 1))
+            xh_q = (q(xb(x.astype(np.float64)) / s_x) * s_x).reshape(M, K)
+            s_l = s_x / (2048.0 if a_mode.endswith("11") else 4096.0)
+            xl_q = (q(xb(xl) / s_l) * s_l).reshape(M, K)
         y = main + xl_q @ wh_q + xh_q @ wl_q
         e = y - ref
         return np.abs(e).max(), e.std()
 
     for fmt, a_mode, w_fmt in (("fp8", "fixed", None), ("fp8", "block", None), ("fp6", "fixed", None), ("fp6", "block", None),
-                               ("fp6", "block2", None), ("bf6", "fixed", None), ("bf6", "block", None), ("fp4", "block", None)):
+                               ("fp6", "block2", None), ("fp6", "exp2_11", None), ("fp6", "exp2_12", None), ("fp6", "exp1_11", None), ("bf6", "fixed", None), ("bf6", "block", None), ("fp4", "block", None)):
         mx, rms = corr(fmt, a_mode, w_fmt)
         print("  correction %-4s  A scales %-6s  linear error max %.2e  rms %.2e" % (fmt, a_mode, mx, rms))
 
