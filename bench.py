@@ -34,6 +34,8 @@ MFMA_F32_PEAK_TF = 157.3     # f32-input MFMA peak
 SURVEY_8D_BYTES_PER_LAYER = 822873092   # 2*4*N*H + 4(N+1) + 4E + 4*B*H + 4H^2 + 4H
 
 ISSUE_NOTE = {
+    "f16mx6": "the f16mx6 linear spends 96 matrix-pipe cycles per 32x32x32 block (64 fp16 + 32 block-scaled fp6) where plain "
+              "bf16 spends 64, so its ceiling on this peak is 2/3 (1667 TFLOP/s)",
     "bf16x3": "the bf16x3 linear issues 3 bf16 MFMA flops per algorithmic flop, so its ceiling on this peak is 1/3 "
               "(833 TFLOP/s)",
     "f16mx8": "the f16mx8 linear spends 128 matrix-pipe cycles per 32x32x32 block (64 fp16 + 64 block-scaled fp8) "
@@ -41,7 +43,7 @@ ISSUE_NOTE = {
     "fp32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
     "f16": "plain fp16 MFMA: one matrix-pipe flop per algorithmic flop",
 }
-DTYPE_NOTE = {"fp32": "f32", "bf16x3": "f32 (bf16x3 MFMA split, fp32 accumulate)", "f16": "f16 (fp16 MFMA, fp32 accumulate)",
+DTYPE_NOTE = {"f16mx6": "f32 (fp16 MFMA + block-scaled fp6 correction MFMA, fp32 accumulate)", "fp32": "f32", "bf16x3": "f32 (bf16x3 MFMA split, fp32 accumulate)", "f16": "f16 (fp16 MFMA, fp32 accumulate)",
               "f16mx8": "f32 (fp16 MFMA + block-scaled fp8 correction MFMA, fp32 accumulate)"}
 
 
@@ -64,7 +66,7 @@ def parse():
     ap.add_argument("--hidden", type=int, default=None)
     ap.add_argument("--degree", type=float, default=None)
     ap.add_argument("--precision", default=os.environ.get("GGCN_PRECISION"),
-                    choices=["f16mx8", "bf16x3", "fp32", "f16"],
+                    choices=["f16mx8", "f16mx6", "bf16x3", "fp32", "f16"],
                     help="arithmetic of the dense linear of the TIMED run; all three meet the 1e-4 parity gate "
                          "(tests/test_gpu_parity.py) and the other two are timed beside it (alt_precisions)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
@@ -571,7 +573,7 @@ def main():
         ref64 = block_float64(x_cpu[:ns].float(), sub_adj, g1_cpu[:ns], g2_cpu[:ns], t_(w1), t_(b1), t_(w2), t_(b2),
                               one_layer)
         xs, g1s, g2s = x[:ns].contiguous(), g1[:ns].contiguous(), g2[:ns].contiguous()
-        precs = ["f16", "f16mx8", "bf16x3"] if half else ["f16mx8", "bf16x3", "fp32"]
+        precs = ["f16", "f16mx8", "bf16x3"] if half else ["f16mx8", "f16mx6", "bf16x3", "fp32"]
         for prec in precs:
             set_mode(prec, args.path)
             with torch.no_grad():
@@ -645,6 +647,15 @@ def main():
             result["gather_check"] = gather_check
         if alt is not None:
             result["alt_precisions"] = alt
+            if not one_layer:   # what a drop-in user gets without opting in: the module's default arithmetic
+                dflt = pkg.GraphConvolution(8, 8, opt=None).precision
+                result["product_default"] = dict(alt.get(dflt, {}), precision=dflt,
+                                                 forward_hbm_frac=(total_fwd_bytes / (alt[dflt]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                                   if dflt in alt else None),
+                                                 headline_precision_is_opt_in=(args.precision != dflt),
+                                                 note="GraphConvolution's default keeps the whole fp32 exponent range; the headline's "
+                                                      "%s needs finite |x|, |w| < 65504 and is chosen per layer (opt.ggcn_precision / "
+                                                      "GGCN_PRECISION / module.precision)" % args.precision)
             result["max_abs_err"] = {"precision": args.precision, "value": alt[args.precision]["max_abs_err_vs_float64"],
                                      "against": "float64 evaluation of the reference formulas on the first %d graphs of the "
                                                 "timed inputs (x1, y1, x, out); parity gate %s" %
