@@ -74,17 +74,34 @@ class GatedGCNEventDetector(nn.Module):
         aspect = x[rows, anchor]                                            # :615-618
         x = x.contiguous()
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if not grad:
+        dropping = self.training and self.dropout.p > 0     # the reference drops whenever the module is in training mode
+        if not grad and not dropping:
             # ---- inference: everything from `aspect` to `scores` on the HIP path, gates kept [B,H] ----
             gate1, gate2 = gate_mlps(aspect.contiguous(), self.gate1, self.gate2)     # :562-571,621-622, one launch
             r = gated_gcn_block(x, adj, gate1, gate2, self.gc1, self.gc2)             # :626-640, one launch (T <= 32)
             logits = self.dense(torch.cat([anchor_rep, aspect, r["out"]], dim=1))     # :642-643 (dropout = identity)
             scores, kl = scores_and_kl(r["x"], aspect, logits, self.fc[0], dist)      # :645-648, one launch
             return logits, r["xy"], kl, scores
-        if self.training and self.dropout.p > 0:
-            # ---- training with dropout: the reference drops entries of the REPEATED [B,T,H] gates (:621-625), one
-            # mask per token, so the gate multiply and the max cannot ride on a [B,H] gate.  The two layers run on
-            # the HIP path (forward and backward); gating, dropout and the pools are the reference's own ops. ----
+        csr = adj if not isinstance(adj, torch.Tensor) else self.gc1._as_csr(adj, x)
+        if dropping and self.gc1.takes_dropout_path(x, csr) and self.gc2.takes_dropout_path(x, csr):
+            # ---- training with dropout, graphs of <= 32 nodes: the reference drops entries of the REPEATED [B,T,H] gates
+            # (:621-625), one draw per token and feature.  The layers draw those keep factors in their own epilogues from a
+            # counter-based hash of (seed, element) -- stream 1 for gate1, stream 2 for gate2 in BOTH layers, as the
+            # reference's one dropped copy of gate2 serves :631 and :639 -- and again in the backward pass: nothing of
+            # size [B,T,H] is materialised for the gates, and the pools stay in the layer launches. ----
+            p = float(self.dropout.p)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # CPU generator: follows torch.manual_seed, no device sync
+            g1, g2 = self.gate1(aspect).contiguous(), self.gate2(aspect).contiguous()
+            gcn1, x1, y1 = self.gc1.forward_gated(x, csr, pool_gate_a=g1, pool_gate_b=g2, want_pool_a=True, want_pool_b=True,
+                                                  dropout=(p, seed, (0, 1, 2)))          # :626-636
+            xy = (x1 * y1).sum(1).mean()                                               # :638
+            xg, out, _ = self.gc2.forward_gated(gcn1, csr, store_gate=g2, pool_gate_a=g2, want_pool_a=True,
+                                                dropout=(p, seed, (2, 2, 0)))            # :639-640
+            if pooled is not None:
+                self.dropout(pooled)                                                   # :641 (unused; keeps the RNG stream)
+        elif dropping:
+            # ---- longer graphs (or a layer off the one-launch path): gating, dropout and the pools as the reference's own
+            # ops around the two HIP layers (three [B,T,H] temporaries) ----
             gate1 = self.dropout(self.gate1(aspect)[:, None, :].expand(-1, T, -1))     # :621-624 (repeat, then dropout)
             gate2 = self.dropout(self.gate2(aspect)[:, None, :].expand(-1, T, -1))
             gcn1 = self.gc1(x, adj)                                                    # :626

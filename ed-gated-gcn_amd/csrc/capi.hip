@@ -2,6 +2,7 @@
 // Argument checking lives here and in the per-kernel launchers; nothing in this
 // library allocates, frees, copies to the host or synchronises.
 #include "common.h"
+#include "dropout_hash.h"
 
 #include <cstring>
 
@@ -180,6 +181,37 @@ int ggcn_gate_pool_backward(const float *out, int64_t ldo, const float *store_ga
 {
     return gate_pool_backward(out, ldo, store_gate, gate_a, gate_b, d_out, ldd, d_pa, d_pb, B, T, F, dY, ldy, d_sg,
                               d_ga, d_gb, d_bsum, as_stream(stream));
+}
+
+int ggcn_gate_pool_backward_drop(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
+                                 const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
+                                 const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
+                                 float *d_ga, float *d_gb, float *d_bsum, float p, uint64_t seed, int sel_store,
+                                 int sel_a, int sel_b, ggcn_stream_t stream)
+{
+    if (!(p >= 0.0f && p < 1.0f) || sel_store < 0 || sel_store > 2 || sel_a < 0 || sel_a > 2 || sel_b < 0 || sel_b > 2)
+        return fail(GGCN_EINVAL, "ggcn_gate_pool_backward_drop: p=%g streams %d %d %d", (double)p, sel_store, sel_a, sel_b);
+    const DropSpec d = make_drop_spec(p, seed, sel_store, sel_a, sel_b);
+    return gate_pool_backward(out, ldo, store_gate, gate_a, gate_b, d_out, ldd, d_pa, d_pb, B, T, F, dY, ldy, d_sg,
+                              d_ga, d_gb, d_bsum, as_stream(stream), &d);
+}
+
+int ggcn_layer_fused_drop(const float *X, int64_t ldx, const void *wpack, const void *graph_ops,
+                          const float *bias, int B, int T, int K, int F, const float *store_gate,
+                          const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
+                          float *pool_a, float *pool_b, int precision, float p, uint64_t seed, int sel_store,
+                          int sel_a, int sel_b, ggcn_stream_t stream)
+{
+    if (!(p >= 0.0f && p < 1.0f) || sel_store < 0 || sel_store > 2 || sel_a < 0 || sel_a > 2 || sel_b < 0 || sel_b > 2)
+        return fail(GGCN_EINVAL, "ggcn_layer_fused_drop: p=%g streams %d %d %d", (double)p, sel_store, sel_a, sel_b);
+    const DropSpec d = make_drop_spec(p, seed, sel_store, sel_a, sel_b);
+    return layer_fused(X, ldx, wpack, nullptr, graph_ops, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out,
+                       ldo, pool_a, pool_b, nullptr, nullptr, nullptr, precision, as_stream(stream), &d);
+}
+
+int ggcn_dropout_mask(int64_t rows, int F, float p, uint64_t seed, int stream_id, float *mask, ggcn_stream_t stream)
+{
+    return dropout_mask(rows, F, p, seed, stream_id, mask, as_stream(stream));
 }
 
 size_t ggcn_colsum_workspace_bytes(int F) { return colsum_workspace_bytes(F); }

@@ -9,6 +9,7 @@
 
 namespace ggcn {
 
+struct DropSpec;
 constexpr int kWave = 64;  // CDNA wavefront
 
 // Thread-local message behind ggcn_last_error().
@@ -71,7 +72,9 @@ int graph_operands(const uint32_t *rowmask, int B, int T, void *ops, hipStream_t
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops, const float *bias,
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,
-                float *overlap_partial, const float *overlap_in, float *overlap_out, int precision, hipStream_t st);
+                float *overlap_partial, const float *overlap_in, float *overlap_out, int precision, hipStream_t st,
+                const struct DropSpec *drop = nullptr);
+int dropout_mask(int64_t rows, int F, float p, uint64_t seed, int sel, float *out, hipStream_t st);
 
 int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
                 const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
@@ -82,7 +85,7 @@ int overlap_reduce(const float *partials, int B, int F, float *xy, hipStream_t s
 int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                        const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                        const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
-                       float *d_ga, float *d_gb, float *d_bsum, hipStream_t st);
+                       float *d_ga, float *d_gb, float *d_bsum, hipStream_t st, const struct DropSpec *drop = nullptr);
 size_t colsum_workspace_bytes(int F);
 int colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *workspace, hipStream_t st);
 

@@ -330,17 +330,19 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             GGCN_SB();
         }
         // the MX operand of W = {fp8(wh) made here from the fp16 fragments, fp8(wl) as loaded}; b0/b1 are
-        // dead afterwards and take the next stage's fragments
+        // dead afterwards and take the next stage's fragments.  The second column tile's converts sit behind the first
+        // tile's first MX MFMA (GGCN_LAB_WH8 = 0: both tiles' converts in front of the MX phase, the round-2 order)
         i32x8 bm[RN];
-#pragma unroll
-        for (int j = 0; j < RN; ++j) {
+        auto make_bm = [&](int j) {
             if GGCN_ON(32) {
                 const i32x4 w = wh8_of(b0[j], b1[j], sq[j]);
                 bm[j] = i32x8{w[0], w[1], w[2], w[3], bq[j][0], bq[j][1], bq[j][2], bq[j][3]};
             } else {
                 bm[j] = lab_bm[j];
             }
-        }
+        };
+        make_bm(0);
+        if constexpr (!(GGCN_LAB_WH8)) make_bm(1);
         GGCN_SB();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -349,6 +351,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             GGCN_SB();
             acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[0], acc[i][0], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[0]);
             GGCN_SB();
+            if constexpr (GGCN_LAB_WH8) { if (i == 0) make_bm(1); }
             if GGCN_ON(16) { if (i == 0) load_bf(kstage(st + 1), b0, b1); }  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
             GGCN_SB();
             acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[1], acc[i][1], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[1]);

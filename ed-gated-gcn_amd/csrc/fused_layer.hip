@@ -37,6 +37,7 @@
 // pooled); T > 32 or weighted adjacency -> the unfused path (linear + aggregate.hip).
 #include "f16mx8_core.h"
 #include "f16mx6_core.h"
+#include "dropout_hash.h"
 #include "lab_hooks.h"
 
 namespace ggcn {
@@ -69,6 +70,7 @@ struct FusedArgs {
     int B, T, K, F;
     int g_tiles, n_wg, n_parts, k_steps;
     LayerPart part[2];
+    DropSpec drop;              // training-mode keep masks of the gates (thr = 0: none); one part only
 };
 
 // acc -> two bf16 planes (hi + lo, residual <= 2^-17 |v|) as B-operand fragments of the two k-steps
@@ -293,7 +295,7 @@ __device__ __forceinline__ void stage_epilogue_operands(const FusedArgs &a, cons
 // MID: the block's second layer through W12 (two aggregations with the `mid` bias in between); OUT: the [N,F] output is
 // stored.  Per graph: both column tiles are split, multiplied by the adjacency and finished side by side, so that one
 // tile's element-wise work issues under the other's MFMA chain.
-template <int SCH, bool FULLT, bool VST, bool MID, bool OUT, int BASE = kLdsBytes>
+template <int SCH, bool FULLT, bool VST, bool MID, bool OUT, int BASE = kLdsBytes, bool DROP = false>
 __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp, f32x16 (&acc)[4][RN], int g0, int nt0,
                                          int n_tiles_total, char *lds, int tid)
 {
@@ -399,33 +401,54 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
             const int gn = (nt0 + j) * NT + c;
             // a gate is constant over the rows of a graph and rounding is monotonic, so
             // max_t fl(y_t * g) == fl(g * max_t y_t) for g >= 0 (and g * min_t y_t for g < 0):
-            // track max and min of y once, apply both pool gates at the end (bert_amir5.py:635-640)
-            float vmax = -INFINITY, vmin = INFINITY;
+            // track max and min of y once, apply both pool gates at the end (bert_amir5.py:635-640).
+            // DROP (training, bert_amir5.py:621-625): every (token, feature) has its own keep factor per gate stream, so
+            // the gated values themselves are maximised.
+            float vmax = -INFINITY, vmin = INFINITY, pmax_a = -INFINITY, pmax_b = -INFINITY;
             float *tile = OUT ? out + ((int64_t)g * T) * ldo + (nt0 + j) * NT : nullptr;  // wave-uniform
             const float sg = vsg[j];
             const float bj = vb[j];
+            const uint32_t didx0 = DROP ? (uint32_t)(((int64_t)g * T + 4 * h) * F + gn) : 0u;   // element of row 4h; rows add row0 * F
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
                 const float v = y[j][r] * rinv[r] + bj;   // gcn.py:41,43
+                float vs = v * sg;
+                if constexpr (DROP) {
+                    const uint32_t hh = drop_hash(didx0 + (uint32_t)(row0 * F), a.drop.seed_lo, a.drop.seed_hi);
+                    vs *= drop_keep(hh, a.drop.sel[0], a.drop.thr, a.drop.scale);
+                    if (FULLT || row0 + 4 * h < T) {
+                        pmax_a = fmaxf(pmax_a, v * vga[j] * drop_keep(hh, a.drop.sel[1], a.drop.thr, a.drop.scale));
+                        pmax_b = fmaxf(pmax_b, v * vgb[j] * drop_keep(hh, a.drop.sel[2], a.drop.thr, a.drop.scale));
+                    }
+                }
                 if constexpr (vst) {
                     // staged for the 16-byte row stores below; columns of the rows with bit 2 set are
                     // swapped between the two 32-column halves so that h = 0 / 1 hit different banks
-                    stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = v * sg;
+                    stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = vs;
                 }
                 if (FULLT || row0 + 4 * h < T) {
-                    if (direct_store && col_ok[j]) tile[lane_off + row0 * ldo] = v * sg;  // bert_amir5.py:626 / :639
-                    vmax = fmaxf(vmax, v);
-                    vmin = fminf(vmin, v);
+                    if (direct_store && col_ok[j]) tile[lane_off + row0 * ldo] = vs;  // bert_amir5.py:626 / :639
+                    if constexpr (!DROP) {
+                        vmax = fmaxf(vmax, v);
+                        vmin = fminf(vmin, v);
+                    }
                 }
             }
             // the other lane half's value: v_permlane32_swap (one VALU instruction; __shfl_xor(.., 32) is a
             // ds_bpermute, an LDS round trip in front of the pooled stores).  Only lanes 0-31 use the result.
-            vmax = fmaxf(vmax, upper_half_to_lower(vmax));
-            vmin = fminf(vmin, upper_half_to_lower(vmin));
-            if (h == 0 && col_ok[j]) {
+            float pa, pb;
+            if constexpr (DROP) {
+                pa = fmaxf(pmax_a, upper_half_to_lower(pmax_a));
+                pb = fmaxf(pmax_b, upper_half_to_lower(pmax_b));
+            } else {
+                vmax = fmaxf(vmax, upper_half_to_lower(vmax));
+                vmin = fminf(vmin, upper_half_to_lower(vmin));
                 const float ga = vga[j], gb = vgb[j];
-                const float pa = ga * (ga >= 0.0f ? vmax : vmin), pb = gb * (gb >= 0.0f ? vmax : vmin);
+                pa = ga * (ga >= 0.0f ? vmax : vmin);
+                pb = gb * (gb >= 0.0f ? vmax : vmin);
+            }
+            if (h == 0 && col_ok[j]) {
                 if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
                 if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
                 dot = fmaf(pa, pb, dot);
@@ -535,7 +558,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
     // `mid` and `out` are workgroup-uniform run-time facts (the W1 / W12 tiles of the block): four straight-line
     // epilogues instead of scalar branches inside one -- a branch per tile ends the basic block, and nothing (the
     // other column tile's split, the next graph's loads) can then be scheduled into the shadow of a tile's MFMA chain
-    if (lp.mid) {
+    if (a.drop.thr != 0) {   // training with dropout on the gates: one layer per launch (no mid bias)
+        if (lp.out) epilogue<SCH, FULLT, VST, false, true, kLdsBytes, true>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid);
+        else epilogue<SCH, FULLT, VST, false, false, kLdsBytes, true>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid);
+    } else if (lp.mid) {
         if (lp.out) epilogue<SCH, FULLT, VST, true, true>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid);
         else epilogue<SCH, FULLT, VST, true, false>(a, lp, acc, g0, nt0, n_tiles_total, lds, tid);
     } else {
@@ -929,6 +955,10 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
     const bool kfull = (a.K % BK == 0);
     a.k_steps = round_up(a.K, BK) / KSTEP;
     a.n_wg = (a.F + BN - 1) / BN;
+    if (a.drop.thr != 0 && (a.T > 32 || a.n_parts != 1 || precision == GGCN_PREC_F16MX6))
+        return fail(GGCN_EUNSUPPORTED, "%s: gate dropout is built into the one-launch layer of graphs of <= 32 nodes (bf16x3 / f16mx8)", who);
+    if ((int64_t)a.B * a.T * a.F >= ((int64_t)1 << 32) && a.drop.thr != 0)
+        return fail(GGCN_EUNSUPPORTED, "%s: gate dropout indexes elements with 32 bits (B*T*F = %lld)", who, (long long)a.B * a.T * a.F);
     if (a.T > 32 && precision == GGCN_PREC_F16MX6)
         return fail(GGCN_EUNSUPPORTED, "%s: f16mx6 takes graphs of <= 32 nodes (T=%d); use f16mx8", who, a.T);
     if (a.T > 32) {   // 64-, 128- or 256-row graph slots: layer_fused_wide_kernel
@@ -1004,6 +1034,24 @@ int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint
     return check_launch("ggcn_csr_rowmask");
 }
 
+__global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t n, int F, DropSpec d, int sel, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = drop_keep(drop_hash((uint32_t)i, d.seed_lo, d.seed_hi), sel, d.thr, d.scale);
+}
+
+int dropout_mask(int64_t rows, int F, float p, uint64_t seed, int sel, float *out, hipStream_t st)
+{
+    if (!out) return fail(GGCN_EINVAL, "ggcn_dropout_mask: null pointer");
+    if (rows <= 0 || F <= 0 || sel < 0 || sel > 2 || !(p >= 0.0f && p < 1.0f))
+        return fail(GGCN_EINVAL, "ggcn_dropout_mask: rows=%lld F=%d sel=%d p=%g", (long long)rows, F, sel, (double)p);
+    const int64_t n = rows * F;
+    if (n >= ((int64_t)1 << 32)) return fail(GGCN_EUNSUPPORTED, "ggcn_dropout_mask: rows*F must fit 32 bits");
+    const DropSpec d = make_drop_spec(p, seed, 0, 0, 0);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, F, d, sel, out);
+    return check_launch("ggcn_dropout_mask");
+}
+
 int graph_operands(const uint32_t *rowmask, int B, int T, void *ops, hipStream_t st)
 {
     if (!rowmask || !ops) return fail(GGCN_EINVAL, "ggcn_graph_operands: null pointer");
@@ -1018,7 +1066,8 @@ int graph_operands(const uint32_t *rowmask, int B, int T, void *ops, hipStream_t
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops,
                 const float *bias, int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,
-                float *overlap_partial, const float *overlap_in, float *overlap_out, int precision, hipStream_t st)
+                float *overlap_partial, const float *overlap_in, float *overlap_out, int precision, hipStream_t st,
+                const DropSpec *drop)
 {
     if ((overlap_in == nullptr) != (overlap_out == nullptr))
         return fail(GGCN_EINVAL, "ggcn_layer_fused: overlap_in and overlap_out go together");
@@ -1027,6 +1076,7 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
     a.X = X; a.ldx = ldx; a.rowmask = rowmask; a.graph_ops = static_cast<const char *>(graph_ops);
     a.ov_in = overlap_in; a.ov_out = overlap_out;
     a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = 1;
+    if (drop) a.drop = *drop;
     a.part[0] = LayerPart{static_cast<const char *>(wpack), bias, nullptr, store_gate, pool_gate_a, pool_gate_b,
                           out, pool_a, pool_b, overlap_partial, (int)ldo};
     return launch_fused("ggcn_layer_fused", a, precision, st);

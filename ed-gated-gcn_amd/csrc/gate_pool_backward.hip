@@ -12,17 +12,23 @@
 // Mapping: workgroup = (graph, 256-column slab), thread = one column, loop over the T rows twice
 // (find the maxima, then write dY): coalesced 1 KiB row segments, HBM-bound:
 // 4*N*F (out) [+ 4*N*F d_out] read, 4*N*F (dY) written.
+// DROP (training, bert_amir5.py:621-625): every gate carries a per-(token, feature) keep factor k[t] in {0, 1/(1-p)}
+// (dropout_hash.h; the forward's epilogue draws the same ones): sg, ga, gb above become sg*ks[t], ga*ka[t], gb*kb[t].  A
+// token whose STORE factor is 0 has out[t] = 0 and its y is not recoverable: it is taken as 0, which is exact whenever the
+// pool gates in use share the store gate's stream or there is no store gate -- the block's two cases (:627-640).
 #include "common.h"
+#include "dropout_hash.h"
 
 namespace ggcn {
 namespace {
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void gate_pool_backward_kernel(
     const float *__restrict__ out, int64_t ldo, const float *__restrict__ store_gate,
     const float *__restrict__ gate_a, const float *__restrict__ gate_b,
     const float *__restrict__ d_out, int64_t ldd, const float *__restrict__ d_pa,
     const float *__restrict__ d_pb, int T, int F, int n_slabs, float *__restrict__ dY, int64_t ldy,
-    float *__restrict__ d_sg, float *__restrict__ d_ga, float *__restrict__ d_gb, float *__restrict__ d_bsum)
+    float *__restrict__ d_sg, float *__restrict__ d_ga, float *__restrict__ d_gb, float *__restrict__ d_bsum, DropSpec drop)
 {
     const int b = blockIdx.x / n_slabs;
     const int f = (blockIdx.x - b * n_slabs) * 256 + threadIdx.x;
@@ -38,18 +44,34 @@ __global__ __launch_bounds__(256) void gate_pool_backward_kernel(
 
     float best_a = -INFINITY, best_b = -INFINITY, ya = 0.0f, yb = 0.0f, acc_sg = 0.0f;
     int ia = 0, ib = 0;
+    const uint32_t e0 = DROP ? (uint32_t)((int64_t)b * T * F + f) : 0u;   // element (node b*T + t, feature f) = e0 + t*F
     for (int t = 0; t < T; ++t) {
-        const float y = o[(int64_t)t * ldo] * inv_sg;
-        const float va = y * ga, vb = y * gb;
-        if (va > best_a) { best_a = va; ia = t; ya = y; }
-        if (vb > best_b) { best_b = vb; ib = t; yb = y; }
-        if (d_out) acc_sg = fmaf(d_out[((int64_t)b * T + t) * ldd + f], y, acc_sg);
+        float ks = 1.0f, ka = 1.0f, kb = 1.0f;
+        if constexpr (DROP) {
+            const uint32_t hh = drop_hash(e0 + (uint32_t)t * (uint32_t)F, drop.seed_lo, drop.seed_hi);
+            ks = drop_keep(hh, drop.sel[0], drop.thr, drop.scale);
+            ka = drop_keep(hh, drop.sel[1], drop.thr, drop.scale);
+            kb = drop_keep(hh, drop.sel[2], drop.thr, drop.scale);
+        }
+        const float o_t = o[(int64_t)t * ldo];
+        const float y = DROP ? (ks != 0.0f ? o_t * inv_sg / ks : 0.0f) : o_t * inv_sg;
+        const float va = y * ga * ka, vb = y * gb * kb;
+        if (va > best_a) { best_a = va; ia = t; ya = y * ka; }
+        if (vb > best_b) { best_b = vb; ib = t; yb = y * kb; }
+        if (d_out) acc_sg = fmaf(d_out[((int64_t)b * T + t) * ldd + f], y * ks, acc_sg);
     }
     float bsum = 0.0f;
     for (int t = 0; t < T; ++t) {
-        float g = d_out ? d_out[((int64_t)b * T + t) * ldd + f] * sg : 0.0f;
-        if (d_pa && t == ia) g = fmaf(dpa, ga, g);
-        if (d_pb && t == ib) g = fmaf(dpb, gb, g);
+        float ks = 1.0f, ka = 1.0f, kb = 1.0f;
+        if constexpr (DROP) {
+            const uint32_t hh = drop_hash(e0 + (uint32_t)t * (uint32_t)F, drop.seed_lo, drop.seed_hi);
+            ks = drop_keep(hh, drop.sel[0], drop.thr, drop.scale);
+            ka = drop_keep(hh, drop.sel[1], drop.thr, drop.scale);
+            kb = drop_keep(hh, drop.sel[2], drop.thr, drop.scale);
+        }
+        float g = d_out ? d_out[((int64_t)b * T + t) * ldd + f] * sg * ks : 0.0f;
+        if (d_pa && t == ia) g = fmaf(dpa, ga * ka, g);
+        if (d_pb && t == ib) g = fmaf(dpb, gb * kb, g);
         dY[((int64_t)b * T + t) * ldy + f] = g;
         bsum += g;
     }
@@ -106,7 +128,7 @@ int colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *works
 int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                        const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                        const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
-                       float *d_ga, float *d_gb, float *d_bsum, hipStream_t st)
+                       float *d_ga, float *d_gb, float *d_bsum, hipStream_t st, const DropSpec *drop)
 {
     if (!out || !dY) return fail(GGCN_EINVAL, "ggcn_gate_pool_backward: null pointer");
     if (B <= 0 || T <= 0 || F <= 0)
@@ -116,8 +138,15 @@ int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, c
     const int n_slabs = (F + 255) / 256;
     const int64_t blocks = (int64_t)B * n_slabs;
     if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_gate_pool_backward: grid too large");
-    hipLaunchKernelGGL(gate_pool_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, ldo, store_gate,
-                       gate_a, gate_b, d_out, ldd, d_pa, d_pb, T, F, n_slabs, dY, ldy, d_sg, d_ga, d_gb, d_bsum);
+    if (drop && drop->thr != 0) {
+        if ((int64_t)B * T * F >= ((int64_t)1 << 32))
+            return fail(GGCN_EUNSUPPORTED, "ggcn_gate_pool_backward: gate dropout indexes elements with 32 bits");
+        hipLaunchKernelGGL(gate_pool_backward_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, out, ldo, store_gate,
+                           gate_a, gate_b, d_out, ldd, d_pa, d_pb, T, F, n_slabs, dY, ldy, d_sg, d_ga, d_gb, d_bsum, *drop);
+    } else {
+        hipLaunchKernelGGL(gate_pool_backward_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, out, ldo, store_gate,
+                           gate_a, gate_b, d_out, ldd, d_pa, d_pb, T, F, n_slabs, dY, ldy, d_sg, d_ga, d_gb, d_bsum, DropSpec{});
+    }
     return check_launch("ggcn_gate_pool_backward");
 }
 

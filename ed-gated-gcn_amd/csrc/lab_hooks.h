@@ -20,6 +20,11 @@
 #define GGCN_LAB_OFF 0
 #endif
 
+// f16mx8: 1 = the second column tile's fp16 -> fp8 converts behind the first tile's first MX MFMA
+#ifndef GGCN_LAB_WH8
+#define GGCN_LAB_WH8 0
+#endif
+
 #ifdef GGCN_LAB_TRACE
 // timeline probe: per workgroup {block, HW_ID, XCC_ID, t_start, t_loop_begin, t_loop_end, t_end} in 10 ns ticks
 __device__ unsigned long long ggcn_trace_buf[8192 * 8];

@@ -45,12 +45,12 @@ class _GatedLayerFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, text, weight, bias, store_gate, gate_a, gate_b, layer, csr, want_pa, want_pb):
+    def forward(ctx, text, weight, bias, store_gate, gate_a, gate_b, layer, csr, want_pa, want_pb, dropout=None):
         with torch.no_grad():
             out, pa, pb = layer.forward_gated(text, csr, store_gate=store_gate, pool_gate_a=gate_a,
                                               pool_gate_b=gate_b, want_out=True, want_pool_a=want_pa,
-                                              want_pool_b=want_pb, _internal=True)
-        ctx.layer, ctx.csr = layer, csr
+                                              want_pool_b=want_pb, _internal=True, dropout=dropout)
+        ctx.layer, ctx.csr, ctx.dropout = layer, csr, dropout
         ctx.save_for_backward(text, weight, out, store_gate, gate_a, gate_b)
         ctx.has_bias = bias is not None
         return out, pa, pb
@@ -82,10 +82,18 @@ class _GatedLayerFunction(torch.autograd.Function):
             d_ga = torch.empty(B, F, dtype=torch.float32, device=dev) if (gate_a is not None and need[4] and d_pa is not None) else None
             d_gb = torch.empty(B, F, dtype=torch.float32, device=dev) if (gate_b is not None and need[5] and d_pb is not None) else None
             d_bsum = torch.empty(B, F, dtype=torch.float32, device=dev) if (ctx.has_bias and need[2]) else None
-            _capi.check(lib.ggcn_gate_pool_backward(
-                _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),
-                _capi.ptr(d_out2), F, _capi.ptr(d_pa), _capi.ptr(d_pb), B, T, F, _capi.ptr(dy), F,
-                _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), _capi.ptr(d_bsum), st), "ggcn_gate_pool_backward")
+            if ctx.dropout is None:
+                _capi.check(lib.ggcn_gate_pool_backward(
+                    _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),
+                    _capi.ptr(d_out2), F, _capi.ptr(d_pa), _capi.ptr(d_pb), B, T, F, _capi.ptr(dy), F,
+                    _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), _capi.ptr(d_bsum), st), "ggcn_gate_pool_backward")
+            else:   # the keep factors of the forward launch, drawn again from (seed, element)
+                dp, dseed, (ss, sa, sb) = ctx.dropout
+                _capi.check(lib.ggcn_gate_pool_backward_drop(
+                    _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),
+                    _capi.ptr(d_out2), F, _capi.ptr(d_pa), _capi.ptr(d_pb), B, T, F, _capi.ptr(dy), F,
+                    _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), _capi.ptr(d_bsum), float(dp), int(dseed), ss, sa, sb, st),
+                    "ggcn_gate_pool_backward_drop")
             dh = torch.empty(B * T, F, dtype=torch.float32, device=dev)
             _capi.check(lib.ggcn_aggregate_t(_capi.ptr(dy), F, _capi.ptr(csr_t.rowptr), _capi.ptr(csr_t.colidx),
                                              _capi.ptr(csr_t.vals), _capi.ptr(inv), B, T, F, _capi.ptr(dh), F, st),
@@ -120,7 +128,7 @@ class _GatedLayerFunction(torch.autograd.Function):
                 db = torch.empty(F, dtype=torch.float32, device=dev)
                 ws = torch.empty(lib.ggcn_colsum_workspace_bytes(F), dtype=torch.uint8, device=dev)
                 _capi.check(lib.ggcn_colsum(_capi.ptr(d_bsum), F, B, F, _capi.ptr(db), _capi.ptr(ws), st), "ggcn_colsum")
-        return dx, dw, db, d_sg, d_ga, d_gb, None, None, None, None
+        return dx, dw, db, d_sg, d_ga, d_gb, None, None, None, None, None
 
 
 class GraphConvolution(nn.Module):
@@ -296,9 +304,14 @@ class GraphConvolution(nn.Module):
         return (self.fused and self.precision == "f16" and text.dtype == torch.float16
                 and 128 < csr.T <= self.LONG_MAX_T and self.in_features % 64 == 0 and self.out_features % 8 == 0)
 
+    def takes_dropout_path(self, text, csr):
+        """True when the gates' training-mode dropout (``bert_amir5.py:621-625``) can be drawn inside the layer launch:
+        the one-launch layer for graphs of <= 32 nodes."""
+        return self.takes_fused_path(text, csr) and csr.T <= 32 and text.shape[0] * text.shape[1] * self.out_features < 2 ** 32
+
     def forward_gated(self, text, adj, store_gate=None, pool_gate_a=None, pool_gate_b=None,
                       want_out=True, want_pool_a=False, want_pool_b=False, _internal=False,
-                      overlap_partial=None, overlap_reduce=None):
+                      overlap_partial=None, overlap_reduce=None, dropout=None):
         """Layer + gate + max-pool in one aggregation pass.
 
         Returns ``(out [B,T,F] or None, pool_a [B,F] or None, pool_b [B,F] or None)`` with
@@ -308,7 +321,11 @@ class GraphConvolution(nn.Module):
         One-launch path only (``takes_fused_path``): ``overlap_partial`` (float32 ``[B, ceil(F/64)]``)
         receives this layer's share of ``sum_f pool_a*pool_b``; ``overlap_reduce=(partials, xy)`` makes
         this launch reduce the partials an earlier launch wrote into the scalar ``xy``
-        (``bert_amir5.py:638`` without its own launches)."""
+        (``bert_amir5.py:638`` without its own launches).
+
+        ``dropout=(p, seed, (stream_store, stream_a, stream_b))`` (one-launch path, graphs of <= 32 nodes): the three gates
+        are dropped per (token, feature) like the reference's repeated ``[B,T,H]`` gates (``bert_amir5.py:621-625``);
+        stream 0 = not dropped, 1 / 2 = the two independent Bernoulli streams of ``seed`` (``include/ggcn.h``)."""
         self._check(text)
         if text.shape[0] == 0:   # an empty batch is a valid input of the reference (gcn.py:30-45): empty outputs
             B, T, F = 0, text.shape[1], self.out_features
@@ -320,8 +337,10 @@ class GraphConvolution(nn.Module):
             # training: the same kernels, wrapped in an autograd Function with a HIP backward
             if text.dtype != torch.float32:
                 raise RuntimeError("training through the HIP layer needs float32 features")
+            if dropout is not None and not self.takes_dropout_path(text, csr):
+                raise RuntimeError("dropout= needs the one-launch layer of graphs of <= 32 nodes (takes_dropout_path)")
             out, pa, pb = _GatedLayerFunction.apply(text, self.weight, self.bias, store_gate, pool_gate_a,
-                                                    pool_gate_b, self, csr, want_pool_a, want_pool_b)
+                                                    pool_gate_b, self, csr, want_pool_a, want_pool_b, dropout)
             return (out if want_out else None), pa, pb
         lib = _capi.load_library()
         B, T, _ = text.shape
@@ -338,9 +357,12 @@ class GraphConvolution(nn.Module):
                                        % (name, B, F, tuple(g.shape)))
         half = text.dtype == torch.float16
         use_fused = self.takes_fused_path(text, csr)
+        if dropout is not None and not (use_fused and self.takes_dropout_path(text, csr)):
+            raise RuntimeError("dropout= needs the one-launch layer of graphs of <= 32 nodes (takes_dropout_path)")
         if (overlap_partial is not None or overlap_reduce is not None) and not use_fused:
             raise RuntimeError("overlap_partial / overlap_reduce need the one-launch layer (takes_fused_path)")
-        use_long = (not use_fused) and self.takes_long_path(text, csr) and x2d.data_ptr() % 16 == 0
+        use_long = ((not use_fused) and self.takes_long_path(text, csr) and x2d.data_ptr() % 16 == 0
+                    and x2d.stride(0) % 8 == 0)   # ggcn_layer_fused_h wants 16-byte aligned rows; other views: linear_h + aggregate_h
         hidden = None if (use_fused or use_long) else self.linear(x2d)
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
@@ -348,6 +370,16 @@ class GraphConvolution(nn.Module):
             pa = torch.empty(B, F, dtype=torch.float32, device=dev) if want_pool_a else None
             pb = torch.empty(B, F, dtype=torch.float32, device=dev) if want_pool_b else None
             bias = None if self.bias is None else self.bias.detach()
+            if use_fused and dropout is not None:
+                kprec = "f16mx8" if self.precision == "f16mx6" else self.precision   # the fp6 kernel has no dropout epilogue
+                pack = self._packed_weight(lib, st, precision=kprec)
+                dp, dseed, (ss, sa, sb) = dropout
+                _capi.check(lib.ggcn_layer_fused_drop(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack), _capi.ptr(csr.graph_ops),
+                                                      _capi.ptr(bias), B, T, self.in_features, F, _capi.ptr(store_gate),
+                                                      _capi.ptr(pool_gate_a), _capi.ptr(pool_gate_b), _capi.ptr(out), F,
+                                                      _capi.ptr(pa), _capi.ptr(pb), _capi.PREC[kprec], float(dp), int(dseed),
+                                                      ss, sa, sb, st), "ggcn_layer_fused_drop")
+                return (None if out is None else out.view(B, T, F)), pa, pb
             if use_fused:
                 kprec = self.kernel_precision(x2d, csr)
                 pack = self._packed_weight(lib, st, precision=kprec)

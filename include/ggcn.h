@@ -192,6 +192,14 @@ int ggcn_gate_pool_backward(const float *out, int64_t ldo,
                             const float *d_out, int64_t ldd, const float *d_pa, const float *d_pb,
                             int B, int T, int F, float *dY, int64_t ldy,
                             float *d_sg, float *d_ga, float *d_gb, float *d_bsum, ggcn_stream_t stream);
+/* The same with the gates' dropout keep factors of ggcn_layer_fused_drop (same p, seed and streams as the forward launch):
+ * sg, ga, gb become sg*k_store[t], ga*k_a[t], gb*k_b[t].  A token whose store factor is 0 (out[t] = 0) contributes y = 0:
+ * exact when the pool gates in use share the store gate's stream or there is no store gate (the block's two layers). */
+int ggcn_gate_pool_backward_drop(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
+                                 const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
+                                 const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
+                                 float *d_ga, float *d_gb, float *d_bsum, float p, uint64_t seed, int stream_store,
+                                 int stream_a, int stream_b, ggcn_stream_t stream);
 /* d_bsum (NULL or [B,F]) receives sum_t dY per graph; db = sum_rows dY is then ggcn_colsum over its B rows.
  * ggcn_colsum: out[f] = sum_r X[r,f] for X [M, ld], deterministic (fixed-order slab sums);
  * workspace: ggcn_colsum_workspace_bytes(F) bytes. */
@@ -281,6 +289,23 @@ int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void
                      float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
                      float *x1, float *y1, float *pool_out, float *overlap_partial,
                      int precision, ggcn_stream_t stream);
+/* ---- training-mode dropout of the gates inside the one-launch layer (graphs of <= 32 nodes) ------------------
+ * models/bert_amir5.py:621-625 repeats each gate to [B,T,H] and THEN applies F.dropout: one Bernoulli draw per (token,
+ * feature) and gate.  Here the keep factors k[t,f] in {0, 1/(1-p)} come from a counter-based hash of (seed, element)
+ * (csrc/dropout_hash.h) evaluated in the layer's epilogue -- nothing of size [B,T,H] is materialised -- and again in
+ * the backward pass.  Two independent streams exist per seed (1, 2); a gate slot names the stream that drops it (0 =
+ * not dropped).  The block uses stream 1 for gate1 and stream 2 for gate2 in BOTH layers (the reference drops gate2
+ * once and uses it at :631 and :639):  layer 1: (store 0, pool a 1, pool b 2);  layer 2: (store 2, pool a 2, pool b 0).
+ *   out = y * store_gate * k_store,   pool_x = max_t (y * pool_gate_x * k_x)
+ * precision GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8; B*T*F < 2^32.  ggcn_dropout_mask writes k (rows x F floats) of one
+ * stream: what a test or a host-side oracle multiplies the repeated gate by. */
+int ggcn_layer_fused_drop(const float *X, int64_t ldx, const void *wpack, const void *graph_ops,
+                          const float *bias, int B, int T, int K, int F,
+                          const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
+                          float *out, int64_t ldo, float *pool_a, float *pool_b, int precision,
+                          float p, uint64_t seed, int stream_store, int stream_a, int stream_b, ggcn_stream_t stream);
+int ggcn_dropout_mask(int64_t rows, int F, float p, uint64_t seed, int stream_id, float *mask, ggcn_stream_t stream);
+
 /* models/bert_amir5.py:638 from the partials a ggcn_block_fused / ggcn_layer_fused launch left:
  * *xy = mean_b sum_f x1*y1, fixed summation order (deterministic), one small launch. */
 int ggcn_overlap_reduce(const float *partials, int B, int F, float *xy, ggcn_stream_t stream);

@@ -1116,6 +1116,27 @@ def test_dropin_forward_is_sync_free_and_shares_the_conversion(pkg, dev):
     assert torch.equal(edited, fresh)
 
 
+def test_forward_under_inference_mode(pkg, dev):
+    """torch.inference_mode() tensors track no version counter: the adjacency cache and the weight-image keys must not
+    read `_version` from them (a batch moved to the device inside the context is such a tensor)."""
+    from ed_gated_gcn_amd import synth
+    B, T, H = 8, 31, 64
+    w, b = synth.layer_params(H, H, seed=1)
+    m = _layer(pkg, dev, w, b, "bf16x3")
+    adj_np = synth.dependency_batch(B, T, 3.0, seed=2).astype(np.float32)
+    x_cpu = torch.randn(B, T, H)
+    with torch.no_grad():
+        want = m(x_cpu.to(dev), torch.from_numpy(adj_np).to(dev))
+    with torch.inference_mode():
+        x, adj = x_cpu.to(dev), torch.from_numpy(adj_np).to(dev)     # inference tensors
+        assert adj.is_inference()
+        got = m(x, adj)
+        got2 = m(got, adj)                                           # gc2 of a forward: the same adjacency again
+        g = torch.sigmoid(torch.randn(B, H, device=dev))
+        r = pkg.gated_gcn_block(x, adj, g, g, m, m)
+    assert torch.equal(got, want) and got2.shape == got.shape and torch.isfinite(r["out"]).all()
+
+
 def test_f16mx8_range_validation_is_loud(pkg, dev):
     """f16mx8 is opt-in and saturates beyond the fp16 range; validate_range() is the explicit check."""
     import types
@@ -1328,23 +1349,114 @@ def test_training_dropout_masks_the_gates_per_token(pkg, dev):
     inputs = _ace_batch(rng, 32, 31, 60)
     inputs = {k: v.to(dev) for k, v in inputs.items()}
     seen = {}
-    orig = torch.max
+    orig = m.gc1.forward_gated
 
-    def spy(*a, **k):
+    def spy(*a, **k):                                      # x1 = the first pool of layer 1 (bert_amir5.py:627-635)
         r = orig(*a, **k)
-        if len(a) == 2 and a[1] == 1 and a[0].dim() == 3 and "x1" not in seen:
-            seen["x1"] = r[0].detach()
+        assert k.get("dropout") is not None and k["dropout"][2] == (0, 1, 2), "the layer launch draws the gates' keep factors"
+        seen["x1"] = r[1].detach()
         return r
     m.train()
-    torch.max = spy
+    m.gc1.forward_gated = spy
     try:
         logits, xy, kl, scores = m(inputs)
     finally:
-        torch.max = orig
+        m.gc1.forward_gated = orig
     (logits.sum() + xy + kl).backward()                    # the HIP layers train under this path
     assert m.gc1.weight.grad is not None and torch.isfinite(m.gc1.weight.grad).all()
     zero_frac = float((seen["x1"] == 0).float().mean())
     assert zero_frac < 0.02, "pooled features vanish with probability %.2f: the dropout mask is shared by the tokens" % zero_frac
+
+
+# ---------------------------------------------------------------- training-mode dropout of the gates inside the layer launches
+def _drop_mask(pkg, dev, rows, F, p, seed, stream):
+    from ed_gated_gcn_amd import _capi
+    lib = pkg.load_library()
+    m = torch.empty(rows, F, dtype=torch.float32, device=dev)
+    _capi.check(lib.ggcn_dropout_mask(rows, F, float(p), int(seed), stream, _capi.ptr(m), _capi.stream_of(dev)), "ggcn_dropout_mask")
+    return m
+
+
+def test_gate_dropout_masks_are_bernoulli_independent_and_reproducible(pkg, dev):
+    """ggcn_dropout_mask = the keep factors the layer epilogue and the backward pass draw (csrc/dropout_hash.h): values in
+    {0, 1/(1-p)}, dropped fraction p, two independent streams per seed, the same numbers for the same (seed, element)."""
+    rows, F = 4096, 768
+    for p in (0.1, 0.5):
+        m1, m2 = _drop_mask(pkg, dev, rows, F, p, 1234, 1), _drop_mask(pkg, dev, rows, F, p, 1234, 2)
+        for m in (m1, m2):
+            vals = torch.unique(m).cpu().tolist()
+            assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / (1.0 - p)) < 1e-6, vals
+            assert abs(float((m == 0).float().mean()) - p) < 2e-3
+            assert abs(float(m.mean()) - 1.0) < 5e-3                      # an unbiased gate, like F.dropout
+        both = float(((m1 == 0) & (m2 == 0)).float().mean())
+        assert abs(both - p * p) < 2e-3                                   # the two gates' draws are independent
+        assert float((m1[1:] == 0).float().mul((m1[:-1] == 0).float()).mean()) - p * p < 2e-3   # and so are tokens
+        assert torch.equal(m1, _drop_mask(pkg, dev, rows, F, p, 1234, 1))
+        assert not torch.equal(m1, _drop_mask(pkg, dev, rows, F, p, 1235, 1))
+    assert torch.equal(_drop_mask(pkg, dev, 64, 32, 0.5, 7, 0), torch.ones(64, 32, device=dev))
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16mx8", "f16mx6"])
+def test_block_layers_with_gate_dropout_vs_oracle_on_the_exported_masks(pkg, dev, precision):
+    """bert_amir5.py:621-640 in training mode: gates repeated to [B,T,H], dropped per token (:621-625), then :626-640.
+    The two layer launches draw the keep factors themselves (stream 1 = gate1, stream 2 = gate2 in both layers); the oracle
+    gets the same factors from ggcn_dropout_mask and evaluates the reference's formulas -- forward and, through torch
+    autograd, backward."""
+    from ed_gated_gcn_amd import synth
+    B, T, H, p, seed = 12, 31, 128, 0.5, 2 ** 40 + 99
+    rng = np.random.default_rng(5)
+    adj = synth.dependency_batch(B, T, 3.5, seed=8, lengths=rng.integers(4, T + 1, size=B))
+    t = torch.from_numpy
+    x = t(rng.standard_normal((B, T, H)).astype(np.float32))
+    g1 = torch.sigmoid(t(rng.standard_normal((B, H)).astype(np.float32)))
+    g2 = torch.sigmoid(t(rng.standard_normal((B, H)).astype(np.float32)))
+    w1, b1 = synth.layer_params(H, H, seed=1)
+    w2, b2 = synth.layer_params(H, H, seed=2)
+    R1 = t(rng.standard_normal((B, H)).astype(np.float32))
+    R2 = t(rng.standard_normal((B, T, H)).astype(np.float32))
+    gc1, gc2 = _layer(pkg, dev, w1, b1, precision).train(), _layer(pkg, dev, w2, b2, precision).train()
+    xg, g1g, g2g = (v.to(dev).requires_grad_() for v in (x, g1, g2))
+    adj_d = t(adj).to(dev)
+    gcn1, x1, y1 = gc1.forward_gated(xg, adj_d, pool_gate_a=g1g, pool_gate_b=g2g, want_pool_a=True, want_pool_b=True,
+                                     dropout=(p, seed, (0, 1, 2)))
+    xo, out, _ = gc2.forward_gated(gcn1, adj_d, store_gate=g2g, pool_gate_a=g2g, want_pool_a=True, dropout=(p, seed, (2, 2, 0)))
+    xy = (x1 * y1).sum(1).mean()
+    ((out * R1.to(dev)).sum() + 0.1 * (xo * R2.to(dev)).sum() + 0.01 * xy).backward()
+
+    k1 = _drop_mask(pkg, dev, B * T, H, p, seed, 1).view(B, T, H).cpu()
+    k2 = _drop_mask(pkg, dev, B * T, H, p, seed, 2).view(B, T, H).cpu()
+    xr, g1r, g2r = x.clone().requires_grad_(), g1.clone().requires_grad_(), g2.clone().requires_grad_()
+    w1r, b1r, w2r, b2r = (t(v).clone().requires_grad_() for v in (w1, b1, w2, b2))
+    a = t(adj).float()
+    gate1 = g1r[:, None, :] * k1                                           # :621-624: repeat, then dropout
+    gate2 = g2r[:, None, :] * k2
+    gcn1_r = ref_dense.graph_convolution(xr, a, w1r, b1r)                  # :626
+    # a max-pool routes its gradient to the argmax row and a ~1e-5 forward difference can flip a near-tie: the reference
+    # takes the rows the GPU forward selected (that they are maxima of the reference values too is checked below)
+    with torch.no_grad():
+        i1 = (gcn1.detach().cpu() * gate1).argmax(1)
+        i2 = (gcn1.detach().cpu() * gate2).argmax(1)
+        io = xo.detach().cpu().argmax(1)
+    x1_r = (gcn1_r * gate1).gather(1, i1[:, None, :])[:, 0]                # :627-635
+    y1_r = (gcn1_r * gate2).gather(1, i2[:, None, :])[:, 0]                # :631-636
+    xy_r = (x1_r * y1_r).sum(1).mean()                                     # :638
+    xo_r = gate2 * ref_dense.graph_convolution(gcn1_r, a, w2r, b2r)        # :639
+    out_r = xo_r.gather(1, io[:, None, :])[:, 0]                           # :640
+    ((out_r * R1).sum() + 0.1 * (xo_r * R2).sum() + 0.01 * xy_r).backward()
+    tol = TOL[precision]
+    for name, got, want in (("gcn1", gcn1, gcn1_r), ("x1", x1, x1_r), ("y1", y1, y1_r), ("x", xo, xo_r), ("out", out, out_r)):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=0, atol=2 * tol, err_msg=name)
+    with torch.no_grad():   # the gathered rows are maxima of the reference's own values (up to the tolerance)
+        assert float(((gcn1_r * gate1).max(1)[0] - x1_r).abs().max()) <= 2 * tol
+        assert float((xo_r.max(1)[0] - out_r).abs().max()) <= 2 * tol
+    assert abs(float(xy.detach()) - float(xy_r.detach())) <= 1e-3 * max(1.0, abs(float(xy_r.detach())))
+    for name, got, want in (("d x", xg.grad, xr.grad), ("d gate1", g1g.grad, g1r.grad), ("d gate2", g2g.grad, g2r.grad),
+                            ("d W1", gc1.weight.grad, w1r.grad), ("d b1", gc1.bias.grad, b1r.grad),
+                            ("d W2", gc2.weight.grad, w2r.grad), ("d b2", gc2.bias.grad, b2r.grad)):
+        _grad_close(got, want, name, rel=5e-4)
+    # half of the gate entries really were dropped, per token: a pooled feature of an all-positive gcn1 would vanish only
+    # when all T tokens lose it
+    assert 0.45 < float((k1 == 0).float().mean()) < 0.55
 
 
 # ---------------------------------------------------------------- one launch per layer for 32 < T <= 256 (LitBank: ORI_ML = 100, ACE cased: 231)
