@@ -36,14 +36,23 @@ class LegacyBertAdapter(nn.Module):
 
 
 class GatedGCNEventDetector(nn.Module):
+    """``BertAmir55`` (VARIANT "55").  Subclasses mirror the other live models of ``train.py:268-282`` around the same
+    block: ``GatedGCNEventDetector54`` = ``BertAmir54`` (``bert_amir5.py:434``: two-layer ``dense`` on [aspect, out,
+    pooled], a Sigmoid in front of ``fc``), ``GCNEventDetectorNoGate`` = ``BertAmir55NoGate`` (``:654``: the two layers
+    without gates; ``xy`` = 0.0).  Each loads its reference ``state_dict`` unchanged."""
+    VARIANT = "55"
+
     def __init__(self, bert, opt):
-        super().__init__()                                                  # bert_amir5.py:545-571
+        super().__init__()                                                  # bert_amir5.py:545-571 / :435-467 / :655-683
         self.device = getattr(opt, "device", None)
         self.bert = bert
         self.dropout = nn.Dropout(opt.dropout)
         self.hidden_dim = hd = 128
         self.n_layer = 12
-        self.dense = nn.Linear(2 * 2 * hd + 768 * self.n_layer, opt.polarities_dim)
+        if self.VARIANT == "54":
+            self.dense = nn.Sequential(nn.Linear(2 * 2 * hd + 768, 768), nn.Linear(768, opt.polarities_dim))   # :444-447
+        else:
+            self.dense = nn.Linear(2 * 2 * hd + 768 * self.n_layer, opt.polarities_dim)
         self.lstm = nn.LSTM(self.n_layer * 768, hd, bidirectional=True, batch_first=True, num_layers=1)
         self.gc1 = GraphConvolution(2 * hd, 2 * hd, opt)
         self.gc2 = GraphConvolution(2 * hd, 2 * hd, opt)
@@ -51,7 +60,10 @@ class GatedGCNEventDetector(nn.Module):
                                    nn.Linear(hd * 2, hd * 2), nn.Sigmoid())
         self.gate2 = nn.Sequential(nn.Sigmoid(), nn.Linear(hd * 2, hd * 2), nn.Sigmoid(),
                                    nn.Linear(hd * 2, hd * 2), nn.Sigmoid())
-        self.fc = nn.Sequential(nn.Linear(2 * 2 * hd, opt.polarities_dim))
+        if self.VARIANT == "54":
+            self.fc = nn.Sequential(nn.Sigmoid(), nn.Linear(2 * 2 * hd, opt.polarities_dim))                  # :466-467
+        else:
+            self.fc = nn.Sequential(nn.Linear(2 * 2 * hd, opt.polarities_dim))
 
     def forward(self, inputs):
         B = inputs["sentence_length"].shape[0]                              # :579-589
@@ -75,15 +87,30 @@ class GatedGCNEventDetector(nn.Module):
         x = x.contiguous()
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         dropping = self.training and self.dropout.p > 0     # the reference drops whenever the module is in training mode
+        v54, nogate = self.VARIANT == "54", self.VARIANT == "55nogate"
         if not grad and not dropping:
             # ---- inference: everything from `aspect` to `scores` on the HIP path, gates kept [B,H] ----
-            gate1, gate2 = gate_mlps(aspect.contiguous(), self.gate1, self.gate2)     # :562-571,621-622, one launch
-            r = gated_gcn_block(x, adj, gate1, gate2, self.gc1, self.gc2)             # :626-640, one launch (T <= 32)
-            logits = self.dense(torch.cat([anchor_rep, aspect, r["out"]], dim=1))     # :642-643 (dropout = identity)
-            scores, kl = scores_and_kl(r["x"], aspect, logits, self.fc[0], dist)      # :645-648, one launch
-            return logits, r["xy"], kl, scores
+            if nogate:   # :736-752: gc2(gc1(x)) and its max-pool -- the block with unit gates (one launch for T <= 32)
+                ones = x.new_ones(B, 2 * self.hidden_dim)
+                r = gated_gcn_block(x, adj, ones, ones, self.gc1, self.gc2)
+                xy = 0.0
+            else:
+                gate1, gate2 = gate_mlps(aspect.contiguous(), self.gate1, self.gate2)     # :562-571,621-622, one launch
+                r = gated_gcn_block(x, adj, gate1, gate2, self.gc1, self.gc2)             # :626-640, one launch (T <= 32)
+                xy = r["xy"]
+            if v54:      # :531-536: dense on [aspect, out, pooled]; fc = Linear o Sigmoid, and sigmoid(cat) = cat(sigmoid)
+                logits = self.dense(torch.cat([aspect, r["out"], pooled], dim=1))
+                scores, kl = scores_and_kl(torch.sigmoid(r["x"]), torch.sigmoid(aspect), logits, self.fc[1], dist)
+            else:
+                logits = self.dense(torch.cat([anchor_rep, aspect, r["out"]], dim=1))     # :642-643 (dropout = identity)
+                scores, kl = scores_and_kl(r["x"], aspect, logits, self.fc[0], dist)      # :645-648, one launch
+            return logits, xy, kl, scores
         csr = adj if not isinstance(adj, torch.Tensor) else self.gc1._as_csr(adj, x)
-        if dropping and self.gc1.takes_dropout_path(x, csr) and self.gc2.takes_dropout_path(x, csr):
+        if nogate:
+            gcn1 = self.gc1(x, csr)                                                    # :736
+            xg, out, _ = self.gc2.forward_gated(gcn1, csr, want_pool_a=True)           # :748-749
+            xy = 0.0
+        elif dropping and self.gc1.takes_dropout_path(x, csr) and self.gc2.takes_dropout_path(x, csr):
             # ---- training with dropout, graphs of <= 32 nodes: the reference drops entries of the REPEATED [B,T,H] gates
             # (:621-625), one draw per token and feature.  The layers draw those keep factors in their own epilogues from a
             # counter-based hash of (seed, element) -- stream 1 for gate1, stream 2 for gate2 in BOTH layers, as the
@@ -97,7 +124,7 @@ class GatedGCNEventDetector(nn.Module):
             xy = (x1 * y1).sum(1).mean()                                               # :638
             xg, out, _ = self.gc2.forward_gated(gcn1, csr, store_gate=g2, pool_gate_a=g2, want_pool_a=True,
                                                 dropout=(p, seed, (2, 2, 0)))            # :639-640
-            if pooled is not None:
+            if pooled is not None and not v54:
                 self.dropout(pooled)                                                   # :641 (unused; keeps the RNG stream)
         elif dropping:
             # ---- longer graphs (or a layer off the one-launch path): gating, dropout and the pools as the reference's own
@@ -110,16 +137,31 @@ class GatedGCNEventDetector(nn.Module):
             xy = (x1 * y1).sum(1).mean()                                               # :638
             xg = gate2 * self.gc2(gcn1, adj)                                           # :639
             out = torch.max(xg, dim=1)[0]                                              # :640
-            if pooled is not None:
+            if pooled is not None and not v54:
                 self.dropout(pooled)                                                   # :641 (unused; keeps the RNG stream)
         else:
             gate1 = self.gate1(aspect)                                                 # dropout is the identity here
             gate2 = self.gate2(aspect)
             r = gated_gcn_block(x, adj, gate1.contiguous(), gate2.contiguous(), self.gc1, self.gc2)   # :626-640
             xy, xg, out = r["xy"], r["x"], r["out"]
-        out = self.dropout(out)                                             # :642
-        logits = self.dense(torch.cat([anchor_rep, aspect, out], dim=1))    # :643
+        if v54:
+            pooled_d = self.dropout(pooled)                                 # :531
+            out = self.dropout(out)                                         # :532
+            logits = self.dense(torch.cat([aspect, out, pooled_d], dim=1))  # :533
+        else:
+            out = self.dropout(out)                                         # :642
+            logits = self.dense(torch.cat([anchor_rep, aspect, out], dim=1))    # :643
         output_w = self.fc(torch.cat([xg, aspect[:, None, :].expand(-1, T, -1)], dim=2))   # :645
         scores = (logits[:, None, :] * output_w).sum(2)                     # :646
         kl = (torch.softmax(scores, 1) * torch.softmax(dist.float(), 1)).sum(1).mean()          # :648
         return logits, xy, kl, scores
+
+
+class GatedGCNEventDetector54(GatedGCNEventDetector):
+    """``BertAmir54`` (``models/bert_amir5.py:434-541``)."""
+    VARIANT = "54"
+
+
+class GCNEventDetectorNoGate(GatedGCNEventDetector):
+    """``BertAmir55NoGate`` (``models/bert_amir5.py:654-752``)."""
+    VARIANT = "55nogate"

@@ -107,8 +107,11 @@ class _GatedLayerFunction(torch.autograd.Function):
                     pack_t = layer._packed_weight(lib, st, transposed=True)
                     _capi.check(lib.ggcn_linear(_capi.ptr(dh), F, None, 0, _capi.ptr(pack_t), _capi.ptr(dx), K,
                                                 B * T, F, K, _capi.PREC["bf16x3"], st), "ggcn_linear(dX)")
-                else:
-                    wt = weight.detach().t().contiguous()
+                else:   # exact-fp32 mode: W^T as a plain matrix, transposed once per weight update
+                    key = (weight.data_ptr(), tensor_version(weight), weight.device)
+                    if getattr(layer, "_wt_key", None) != key:
+                        layer._wt, layer._wt_key = weight.detach().t().contiguous(), key
+                    wt = layer._wt
                     _capi.check(lib.ggcn_linear(_capi.ptr(dh), F, _capi.ptr(wt), K, None, _capi.ptr(dx), K,
                                                 B * T, F, K, _capi.PREC["fp32"], st), "ggcn_linear(dX)")
                 dx = dx.view(B, T, K)

@@ -22,6 +22,9 @@ Fixtures:
   G3  amir55_block.npz     BertAmir55 in eval(): LSTM output, adj, both gates,
                            gc1/gc2 outputs, xy, logits, kl, scores + the gate
                            MLP / GCN parameters
+  G4  amir55_full.npz      the whole BertAmir55: inputs, seeds, reference outputs
+  G5  amir54_full.npz      BertAmir54 (bert_amir5.py:434) on the same inputs
+  G6  amir55nogate_full.npz  BertAmir55NoGate (bert_amir5.py:654) on the same inputs
 
 Usage:  python oracle/make_golden.py [--ref /root/reference] [--out tests/golden]
 """
@@ -47,8 +50,8 @@ def _import_reference(ref_root):
         sys.modules.setdefault(name, m)
     sys.path.insert(0, ref_root)
     from models.gcn import GraphConvolution          # noqa: E402
-    from models.bert_amir5 import BertAmir55         # noqa: E402
-    return GraphConvolution, BertAmir55
+    from models.bert_amir5 import BertAmir55, BertAmir54, BertAmir55NoGate         # noqa: E402
+    return GraphConvolution, BertAmir55, BertAmir54, BertAmir55NoGate
 
 
 def _reset_params(module, gen):
@@ -226,6 +229,27 @@ def make_g3(BertAmir55, out_dir):
     for k, v in inputs.items():
         full["in_" + k] = v.numpy()
     np.savez_compressed(os.path.join(out_dir, "amir55_full.npz"), **full)
+    return inputs
+
+
+def make_g5(cls, name, inputs, out_dir):
+    """G5 / G6: the other live classifiers of train.py:268-282 (BertAmir54, BertAmir55NoGate) on G4's inputs: the seeds and
+    the reference's outputs (parameters are re-drawn from the seed on the test side)."""
+    gen = torch.Generator().manual_seed(SEED + 4)
+    NCLS = 34
+    opt = types.SimpleNamespace(device="cpu", dropout=0.25, polarities_dim=NCLS)
+    model = cls(_EncoderStandIn(SEED + 3), opt)
+    for child in model.children():                     # train.py:75-84
+        if not isinstance(child, _EncoderStandIn):
+            _reset_params(child, gen)
+    model.eval()
+    with torch.no_grad():
+        logits, xy, kl, scores = model(inputs)
+    full = {"seed_params": np.array(SEED + 4), "seed_encoder": np.array(SEED + 3), "n_class": np.array(NCLS),
+            "logits": logits.numpy(), "xy": np.array(float(xy), dtype=np.float32), "kl": kl.numpy(), "scores": scores.numpy()}
+    for k, v in inputs.items():
+        full["in_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(out_dir, name), **full)
 
 
 def main():
@@ -236,10 +260,12 @@ def main():
     args = ap.parse_args()
     torch.set_num_threads(1)   # one thread: fixtures do not depend on the host's core count
     os.makedirs(args.out, exist_ok=True)
-    GraphConvolution, BertAmir55 = _import_reference(args.ref)
+    GraphConvolution, BertAmir55, BertAmir54, BertAmir55NoGate = _import_reference(args.ref)
     make_g1(GraphConvolution, args.out)
     make_g2(GraphConvolution, args.out)
-    make_g3(BertAmir55, args.out)
+    inputs = make_g3(BertAmir55, args.out)
+    make_g5(BertAmir54, "amir54_full.npz", inputs, args.out)
+    make_g5(BertAmir55NoGate, "amir55nogate_full.npz", inputs, args.out)
     for f in sorted(os.listdir(args.out)):
         print(f, os.path.getsize(os.path.join(args.out, f)))
 

@@ -534,6 +534,39 @@ def test_config5_classifier_golden_reference_logits(pkg, dev, golden_dir):
     assert abs(float(kl) - float(g["kl"])) <= 1e-4
 
 
+@pytest.mark.parametrize("cls_name,oracle_name,fixture", [("GatedGCNEventDetector54", "BertAmir54Oracle", "amir54_full.npz"),
+                                                          ("GCNEventDetectorNoGate", "BertAmir55NoGateOracle", "amir55nogate_full.npz")])
+def test_other_live_classifiers_golden_reference_logits(pkg, dev, golden_dir, cls_name, oracle_name, fixture):
+    """G5 / G6: the HIP-backed mirrors of BertAmir54 (bert_amir5.py:434) and BertAmir55NoGate (:654) -- every model
+    train.py:268-282 can select around this block -- load the reference's state_dict and reproduce the logits the REFERENCE
+    classes produced (1e-3), in inference and, for the training branch, against the oracle restatement with dropout off."""
+    import types
+    import oracle.ref_amir55 as ra
+    g = np.load(os.path.join(golden_dir, fixture))
+    oracle = getattr(ra, oracle_name)(ra.EncoderStandIn(int(g["seed_encoder"])), int(g["n_class"]))
+    oracle.seeded_init(torch.Generator().manual_seed(int(g["seed_params"])))
+    opt = types.SimpleNamespace(device=dev, dropout=0.25, polarities_dim=int(g["n_class"]))
+    model = getattr(pkg, cls_name)(ra.EncoderStandIn(int(g["seed_encoder"])), opt)
+    model.load_state_dict(oracle.state_dict())           # same keys as the reference's state_dict
+    model = model.to(dev).eval()
+    inputs = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    with torch.no_grad():
+        logits, xy, kl, scores = model(inputs)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(scores.cpu().numpy(), g["scores"], rtol=0, atol=1e-2)
+    assert abs(float(xy) - float(g["xy"])) <= 1e-3 * max(1.0, abs(float(g["xy"])))
+    assert abs(float(kl) - float(g["kl"])) <= 1e-4
+    # the autograd branch (train mode with p = 0: MIOpen's LSTM backward wants training mode): same numbers, and the parameters
+    # receive gradients through the HIP layers
+    model.train()
+    model.dropout.p = 0.0
+    logits2, xy2, kl2, scores2 = model(inputs)
+    np.testing.assert_allclose(logits2.detach().cpu().numpy(), g["logits"], rtol=0, atol=1e-3)
+    (logits2.sum() + kl2 + (xy2 if torch.is_tensor(xy2) else 0.0)).backward()
+    assert model.gc1.weight.grad is not None and torch.isfinite(model.gc1.weight.grad).all()
+    assert model.gc2.weight.grad is not None and float(model.gc2.weight.grad.abs().max()) > 0
+
+
 def test_config5_bert_base_end_to_end(pkg, dev):
     """BASELINE configs[4]: randomly-initialised BERT-base (transformers.BertConfig(), no fetch)
     on PyTorch-ROCm + HIP gated GCN on a synthetic ACE-2005-shaped batch; logits within 1e-3 of

@@ -110,3 +110,22 @@ def test_full_classifier_restatement_reproduces_bertamir55(golden_dir):
     np.testing.assert_allclose(scores.numpy(), g["scores"], rtol=0, atol=2e-5)
     assert abs(float(xy) - float(g["xy"])) <= 1e-6 * abs(float(g["xy"]))
     assert abs(float(kl) - float(g["kl"])) <= 1e-6
+
+
+@pytest.mark.parametrize("cls_name,fixture", [("BertAmir54Oracle", "amir54_full.npz"), ("BertAmir55NoGateOracle", "amir55nogate_full.npz")])
+def test_other_live_classifiers_restatements_reproduce_the_reference(golden_dir, cls_name, fixture):
+    """G5 / G6: the restatements of BertAmir54 (bert_amir5.py:434) and BertAmir55NoGate (:654) -- the other models
+    train.py:268-282 can select -- against the outputs the REFERENCE classes produced for the same seeds and inputs."""
+    import oracle.ref_amir55 as ra
+    g = _load(golden_dir, fixture)
+    torch.set_num_threads(1)
+    model = getattr(ra, cls_name)(ra.EncoderStandIn(int(g["seed_encoder"])), int(g["n_class"]))
+    model.seeded_init(torch.Generator().manual_seed(int(g["seed_params"])))
+    model.eval()
+    inputs = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    with torch.no_grad():
+        logits, xy, kl, scores = model(inputs)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(scores.numpy(), g["scores"], rtol=0, atol=2e-5)
+    assert abs(float(xy) - float(g["xy"])) <= 1e-6 * max(1.0, abs(float(g["xy"])))
+    assert abs(float(kl) - float(g["kl"])) <= 1e-6
