@@ -30,7 +30,7 @@
 // Per lane and stage: 4 x ds_read_b128, the maximum of its 16 values and one DPP exchange with the lane that holds the
 // other half (the block's scale), 8 v_cvt_pk_f16_f32 + 16 v_fma_mixlo/hi_f16 (the residual as fp16: 11 of its <= 13 bits),
 // 8 v_pk_mul_f16 (xl * 2^12, so that ONE convert with ONE scale turns [16 x xh | 16 x xl * 2^12] into both blocks' fields),
-// 7 LDS stores.  128 rows x 2 halves = 256 lanes: every wavefront splits in every stage, nobody waits at the barrier for a
+// a 3-dword DPP exchange with the neighbouring lane and 4 LDS stores of 16 bytes.  128 rows x 2 halves = 256 lanes: every wavefront splits in every stage, nobody waits at the barrier for a
 // wavefront with more to do (a first version gave two of the four wavefronts a whole block per lane every other stage:
 // 24 % slower than f16mx8, the other two idling), and the converts' operands are ordinary short-lived values -- no tuple
 // is updated in place (that version needed 50 fixed registers and hand-written asm to keep hipcc from spilling 500).
@@ -94,7 +94,7 @@ __device__ __forceinline__ void mainloop(const float *__restrict__ xtile, uint32
     const int urow = 32 * wave + (lane >> 1), hb = lane & 1;
     const int s_raw = raw_off(urow, 4 * hb);              // chunk 4 hb + c = this address ^ (c << 4)
     const int s_h = a_lds_off(urow, 2 * hb);               // H plane chunks 2 hb, 2 hb + 1 (^ 16)
-    const int s_q0 = a_lds_off(urow, 0), s_q1 = a_lds_off(urow, 1), s_q2 = a_lds_off(urow, 2), s_q3 = a_lds_off(urow, 3);
+    const int s_qa = a_lds_off(urow, 2 * hb);              // Q plane: the even lane stores chunks 0, 1 (xl block), the odd lane 2, 3
     // The split in pieces, so that a stage can place them between its MFMA groups: the state lives in a SplitState.
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -154,20 +154,24 @@ __device__ __forceinline__ void mainloop(const float *__restrict__ xtile, uint32
         const i32x16 src = {(int)t.ph[0], (int)t.ph[1], (int)t.ph[2], (int)t.ph[3], (int)t.ph[4], (int)t.ph[5], (int)t.ph[6], (int)t.ph[7],
                             (int)t.pl[0], (int)t.pl[1], (int)t.pl[2], (int)t.pl[3], (int)t.pl[4], (int)t.pl[5], (int)t.pl[6], (int)t.pl[7]};
         const u32x6 q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, src), t.sx);
-        // q[0..2]: 16 fields of fp6(xh / sx) (block 1 of the row: bytes 12 hb .. of its 24), q[3..5]: fp6(xl / sl) (block 0)
-        if (hb == 0) {
-            *reinterpret_cast<uint2 *>(qp + s_q0) = make_uint2(q[3], q[4]);
-            *reinterpret_cast<uint32_t *>(qp + s_q0 + 8) = q[5];
-            *reinterpret_cast<uint2 *>(qp + s_q2) = make_uint2(q[0], q[1]);
-            *reinterpret_cast<uint32_t *>(qp + s_q2 + 8) = q[2];
-            *reinterpret_cast<uint32_t *>(qp + s_q1 + 8) = (uint32_t)(t.eb - 14);   // E8M0 of sl = sx * 2^-12
-        } else {
-            *reinterpret_cast<uint32_t *>(qp + s_q0 + 12) = q[3];
-            *reinterpret_cast<uint2 *>(qp + s_q1) = make_uint2(q[4], q[5]);
-            *reinterpret_cast<uint32_t *>(qp + s_q2 + 12) = q[0];
-            *reinterpret_cast<uint2 *>(qp + s_q3) = make_uint2(q[1], q[2]);
-            *reinterpret_cast<uint32_t *>(qp + s_q3 + 8) = (uint32_t)(t.eb - 2);    // E8M0 of sx
+        // q[0..2]: this half's 16 fields of fp6(xh / sx) (block 1 of the row), q[3..5]: of fp6(xl / sl) (block 0).  A block's 24
+        // bytes come from two lanes; scattered 4- and 8-byte stores of both (10 store instructions under two exec masks,
+        // 2- to 4-way bank conflicts) cost 67 us of a 700 us launch, so the lanes trade halves through DPP -- the even lane
+        // takes the whole xl block, the odd lane the whole xh block -- and each stores its block and its scale as two
+        // conflict-free 16-byte writes.
+        if constexpr (((GGCN_LAB_OFF) & 4) != 0) { asm volatile("" :: "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5])); return; }
+        uint32_t recv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t send = hb ? q[3 + i] : q[i];      // what the OTHER lane's block lacks
+            recv[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         }
+        // even lane (hb 0): [own xl half | partner's xl half], odd lane: [partner's xh half | own xh half]
+        const uint32_t d0 = hb ? recv[0] : q[3], d1 = hb ? recv[1] : q[4], d2 = hb ? recv[2] : q[5];
+        const uint32_t d3 = hb ? q[0] : recv[0], d4 = hb ? q[1] : recv[1], d5 = hb ? q[2] : recv[2];
+        const uint32_t e8 = (uint32_t)(t.eb - (hb ? 2 : 14));   // E8M0 of sx (xh block) / of sl = sx * 2^-12 (xl block)
+        *reinterpret_cast<uint4 *>(qp + s_qa) = make_uint4(d0, d1, d2, d3);
+        *reinterpret_cast<uint4 *>(qp + (s_qa ^ 16)) = make_uint4(d4, d5, e8, 0u);
     };
     auto split_half = [&](int buf) {   // the whole split in one go (prologue): RAW[buf] -> PLANE[buf]
         SplitState t;
