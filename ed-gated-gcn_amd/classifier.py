@@ -10,9 +10,12 @@ way.  ``forward(inputs) -> (logits, gate_reg, kl_reg, scores)`` like every live 
 head keep the reference's PyTorch ops (they are trained), and with dropout active the gates are dropped per
 token like the reference's (``:621-625``).  BERT, the BiLSTM and ``dense`` stay PyTorch-ROCm.
 """
+import os
+
 import torch
 import torch.nn as nn
 
+from .csr import tensor_version
 from .gated_block import gated_gcn_block
 from .gcn import GraphConvolution
 from .heads import gate_mlps, scores_and_kl
@@ -64,6 +67,38 @@ class GatedGCNEventDetector(nn.Module):
             self.fc = nn.Sequential(nn.Sigmoid(), nn.Linear(2 * 2 * hd, opt.polarities_dim))                  # :466-467
         else:
             self.fc = nn.Sequential(nn.Linear(2 * 2 * hd, opt.polarities_dim))
+        # no precision asked for (opt.ggcn_precision / GGCN_PRECISION): inference picks the faster "f16mx8" whenever the
+        # weights PROVE its fp16 range sufficient for this model (_proved_precision), "bf16x3" otherwise
+        self._auto_precision = getattr(opt, "ggcn_precision", None) is None and "GGCN_PRECISION" not in os.environ
+        self._proved = None
+
+    F16_RANGE_MARGIN = 32752.0   # half of fp16's largest finite value
+
+    def _proved_precision(self, csr):
+        """"f16mx8" when every value that kernel rounds to fp16 is bounded below ``F16_RANGE_MARGIN`` by the weights alone,
+        else "bf16x3".  The block's input is the BiLSTM output (``:610``), |x| < 1 (o * tanh(c)); with a 0/1 adjacency a
+        layer's output is a mean of hidden rows plus the bias (``gcn.py:35,41,43``), so
+        ``|x.W1| <= c1 = colsum|W1|``, ``|gcn1| <= m1 = max(c1 + |b1|)``, ``|gcn1.W2| <= m1 * colsum|W2|``, and for the one-launch
+        block ``|x.W12| + |mid| <= colsum|W1.W2| + |b1.W2|``.  One host read per weight update (cached on the parameters'
+        version counters); weighted adjacencies and inference tensors (no version counter) keep "bf16x3"."""
+        if not csr.is_binary:
+            return "bf16x3"
+        ps = (self.gc1.weight, self.gc1.bias, self.gc2.weight, self.gc2.bias)
+        key = tuple(None if q is None else (q.data_ptr(), tensor_version(q)) for q in ps)
+        if any(k is not None and k[1] is None for k in key):
+            return "bf16x3"
+        if self._proved is None or self._proved[0] != key:
+            with torch.no_grad():
+                w1, w2 = self.gc1.weight.detach().float(), self.gc2.weight.detach().float()
+                b1 = torch.zeros_like(w1[0]) if self.gc1.bias is None else self.gc1.bias.detach().float()
+                c1 = w1.abs().sum(0)
+                m1 = (c1 + b1.abs()).max()
+                w12 = w1 @ w2
+                bound = torch.stack([m1.new_tensor(1.0), m1, m1 * w2.abs().sum(0).max(),
+                                     (w12.abs().sum(0) + (b1 @ w2).abs()).max()]).max()
+                ok = bool(torch.isfinite(bound)) and float(bound) < self.F16_RANGE_MARGIN
+            self._proved = (key, "f16mx8" if ok else "bf16x3")
+        return self._proved[1]
 
     def forward(self, inputs):
         B = inputs["sentence_length"].shape[0]                              # :579-589
@@ -90,6 +125,10 @@ class GatedGCNEventDetector(nn.Module):
         v54, nogate = self.VARIANT == "54", self.VARIANT == "55nogate"
         if not grad and not dropping:
             # ---- inference: everything from `aspect` to `scores` on the HIP path, gates kept [B,H] ----
+            if self._auto_precision:
+                if isinstance(adj, torch.Tensor):
+                    adj = self.gc1._as_csr(adj, x)   # (the block would convert it anyway; identity-cached)
+                self.gc1.precision = self.gc2.precision = self._proved_precision(adj)
             if nogate:   # :736-752: gc2(gc1(x)) and its max-pool -- the block with unit gates (one launch for T <= 32)
                 ones = x.new_ones(B, 2 * self.hidden_dim)
                 r = gated_gcn_block(x, adj, ones, ones, self.gc1, self.gc2)
@@ -105,6 +144,8 @@ class GatedGCNEventDetector(nn.Module):
                 logits = self.dense(torch.cat([anchor_rep, aspect, r["out"]], dim=1))     # :642-643 (dropout = identity)
                 scores, kl = scores_and_kl(r["x"], aspect, logits, self.fc[0], dist)      # :645-648, one launch
             return logits, xy, kl, scores
+        if self._auto_precision:
+            self.gc1.precision = self.gc2.precision = "bf16x3"   # training: the full-range default
         csr = adj if not isinstance(adj, torch.Tensor) else self.gc1._as_csr(adj, x)
         if nogate:
             gcn1 = self.gc1(x, csr)                                                    # :736

@@ -532,6 +532,23 @@ def test_config5_classifier_golden_reference_logits(pkg, dev, golden_dir):
     np.testing.assert_allclose(scores.cpu().numpy(), g["scores"], rtol=0, atol=1e-2)
     assert abs(float(xy) - float(g["xy"])) <= 1e-3 * abs(float(g["xy"]))
     assert abs(float(kl) - float(g["kl"])) <= 1e-4
+    # no precision was asked for: the weights bound every fp16-rounded value of the block far below 65504 (the input is
+    # the BiLSTM's, |x| < 1), so inference took the faster kernel -- with a proof, not a promise
+    assert model._auto_precision and model.gc1.precision == model.gc2.precision == "f16mx8"
+    # weights that no longer prove it: the full-range default, same answer as the oracle restatement with those weights
+    with torch.no_grad():
+        model.gc1.weight.mul_(3.0e3)
+        oracle.gc1.weight.mul_(3.0e3)
+        logits_b, _, _, _ = model(inputs)
+        ref_b = oracle.eval()({k: v.cpu() for k, v in inputs.items()})[0]
+    assert model.gc1.precision == model.gc2.precision == "bf16x3"
+    assert float((logits_b.cpu() - ref_b).abs().max()) <= 1e-3 * max(1.0, float(ref_b.abs().max()))
+    # an explicit choice is never overridden
+    opt2 = types.SimpleNamespace(device=dev, dropout=0.25, polarities_dim=int(g["n_class"]), ggcn_precision="bf16x3")
+    m2 = pkg.GatedGCNEventDetector(EncoderStandIn(int(g["seed_encoder"])), opt2).to(dev).eval()
+    with torch.no_grad():
+        m2(inputs)
+    assert not m2._auto_precision and m2.gc1.precision == "bf16x3"
 
 
 @pytest.mark.parametrize("cls_name,oracle_name,fixture", [("GatedGCNEventDetector54", "BertAmir54Oracle", "amir54_full.npz"),

@@ -11,7 +11,9 @@ B, T, H = int(os.environ.get("LAB_GRAPHS", "256")), 512, 1024
 adj = synth.dependency_batch(B, T, 6.0)
 rp, ci, _ = synth.csr_from_dense_host(adj)
 csr = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
-x = torch.randn(B * T, H, device=dev).half()
+PAD = int(os.environ.get("LAB_LDX_PAD", "0"))
+x = torch.randn(B * T, H + PAD, device=dev).half()[:, :H]
+LDX = H + PAD
 w, b = synth.layer_params(H, H, seed=1)
 w, b = torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)
 g1, g2 = torch.rand(B, H, device=dev), torch.rand(B, H, device=dev)
@@ -33,10 +35,10 @@ for n in names + ["two"]:
 def run(n):
     lib, pack = libs[n]
     if n == "two":
-        rc = lib.ggcn_linear_h(p(x), H, p(pack), p(hid), H, B * T, H, H, 3, None)
+        rc = lib.ggcn_linear_h(p(x), LDX, p(pack), p(hid), H, B * T, H, H, 3, None)
         rc = rc or lib.ggcn_aggregate_h(p(hid), H, p(csr.rowptr), p(csr.colidx), None, p(b), B, T, H, p(g2), p(g1), p(g2), p(out), H, p(pa), p(pb), None)
     else:
-        rc = lib.ggcn_layer_fused_h(p(x), H, p(pack), p(csr.rowptr), p(csr.colidx), None, p(b), B, T, H, H, p(g2), p(g1), p(g2), p(out), H, p(pa), p(pb), None)
+        rc = lib.ggcn_layer_fused_h(p(x), LDX, p(pack), p(csr.rowptr), p(csr.colidx), None, p(b), B, T, H, H, p(g2), p(g1), p(g2), p(out), H, p(pa), p(pb), None)
     assert rc == 0, lib.ggcn_last_error()
 ref = None
 for n in ["two"] + names:
