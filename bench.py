@@ -529,6 +529,15 @@ def main():
         roofline = mfma_line("layer_fused_kernel (block form: both layers of the block in one launch)",
                              "block_fused_kernel:" + args.precision, t, 2 * (lin_flops + agg_flops), fwd_bytes,
                              "one launch per step = 2 layers: 2 x (2*N*K*F + 2*nnz*F) flops, 2 x SURVEY 8(d) bytes")
+        # what THIS kernel has to move: X in, x out, three pools, two gates, the graphs' operand blocks and the two packed
+        # weight images -- SURVEY 8(d)'s figure still holds gcn1's write + read (2 x N*H*4), which the folded block never makes
+        own = N * H * 4 * 2 + 5 * B * H * 4 + B * 2176 + 2 * (H // 32) * (H // 32) * 3328
+        roofline["kernel_bytes_per_launch"] = own
+        if roofline.get("traffic"):
+            roofline["traffic_over_kernel_bytes"] = roofline["traffic"] / own
+        roofline["note"] += ("; compare `traffic` with kernel_bytes_per_launch (X + x + pools + gates + operand blocks + W: what "
+                             "the one-launch block must move), not with algorithmic_bytes_per_launch: the excess is X read "
+                             "by both XCD groups and by three column tiles each through 4 MiB L2s")
     elif "ggcn_layer_fused_h" in kern_us:
         t = statistics.mean(kern_us["ggcn_layer_fused_h"])
         roofline = mfma_line("layer_fused_long_kernel (fp16 linear + LDS neighbour sums, one launch per layer)",

@@ -55,6 +55,13 @@ constexpr int kLdsBytes6 = 65536;                       // two workgroups per CU
 
 #define GGCN_SB6() __builtin_amdgcn_sched_barrier(0)
 
+// 16-byte chunk c of row r inside an H or Q plane ([128 rows][64 B]): the A planes' swizzle (a_lds_off) with bit 0 of the chunk
+// flipped on rows 2, 3 (mod 4).  A ds_write_b128 is served 8 lanes at a time over 32 banks (128 B): the 8 lanes of 4 split rows
+// x 2 halves put rows r and r + 2 on the same banks with the plain swizzle (2-way: SQ_LDS_BANK_CONFLICT 20 % of the LDS
+// cycles); with the extra bit they take the two chunk pairs of the 128-byte window.  The fragment reads (16 lanes over 64 banks)
+// stay conflict-free: rows with equal row & 3 inside a lane group still differ in the chunk.
+__device__ __forceinline__ int p6_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 2) & 3) ^ ((row >> 1) & 1)) << 4); }
+
 // 16-byte chunk c of row r inside a RAW stage
 __device__ __forceinline__ int raw_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
@@ -93,8 +100,8 @@ __device__ __forceinline__ void mainloop(const float *__restrict__ xtile, uint32
     // ---- the split: lane = (row 32 wave + lane / 2, half hb = lane & 1) ----
     const int urow = 32 * wave + (lane >> 1), hb = lane & 1;
     const int s_raw = raw_off(urow, 4 * hb);              // chunk 4 hb + c = this address ^ (c << 4)
-    const int s_h = a_lds_off(urow, 2 * hb);               // H plane chunks 2 hb, 2 hb + 1 (^ 16)
-    const int s_qa = a_lds_off(urow, 2 * hb);              // Q plane: the even lane stores chunks 0, 1 (xl block), the odd lane 2, 3
+    const int s_h = p6_off(urow, 2 * hb);               // H plane chunks 2 hb, 2 hb + 1 (^ 16)
+    const int s_qa = p6_off(urow, 2 * hb);              // Q plane: the even lane stores chunks 0, 1 (xl block), the odd lane 2, 3
     // The split in pieces, so that a stage can place them between its MFMA groups: the state lives in a SplitState.
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -217,13 +224,13 @@ __device__ __forceinline__ void mainloop(const float *__restrict__ xtile, uint32
 
     const int f_row = lane & 31, f_half = lane >> 5;
     auto read_h1 = [&](int buf, int i, int s, f16x8 &a) {   // k-step s of row block i
-        a = *reinterpret_cast<const f16x8 *>(lds + kPlane + buf * 16384 + a_lds_off(f_row + i * 32, 2 * s + f_half));
+        a = *reinterpret_cast<const f16x8 *>(lds + kPlane + buf * 16384 + p6_off(f_row + i * 32, 2 * s + f_half));
     };
     auto read_q = [&](int buf, int i, i32x8 &a, int &sc) {
         const char *qp = lds + kPlane + buf * 16384 + 8192;
         const int row = f_row + i * 32;
-        const i32x4 lo = *reinterpret_cast<const i32x4 *>(qp + a_lds_off(row, 2 * f_half));
-        const i32x4 hi = *reinterpret_cast<const i32x4 *>(qp + a_lds_off(row, 2 * f_half + 1));   // {dwords 4, 5, scale, -}
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(qp + p6_off(row, 2 * f_half));
+        const i32x4 hi = *reinterpret_cast<const i32x4 *>(qp + p6_off(row, 2 * f_half + 1));   // {dwords 4, 5, scale, -}
         a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         sc = hi[2];
     };
