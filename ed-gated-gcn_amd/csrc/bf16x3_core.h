@@ -76,7 +76,7 @@ __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m *
 __device__ __forceinline__ int a_lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
 // staging row of pass p for this thread
 template <typename AT>
-__device__ __forceinline__ int stage_row(int p) { return p * Geom<AT>::RPP + (int)threadIdx.x / Geom<AT>::TPR; }
+__device__ __forceinline__ int stage_row(int p) { return p * Geom<AT>::RPP + (int)(threadIdx.x & (kThreads - 1)) / Geom<AT>::TPR; }
 
 // Block id -> tile.  Observed dispatch (speed only, never correctness): ids round-robin over the
 // 8 XCDs; inside an XCD the first 32 blocks take the 32 CUs in order, the next 32 become their
@@ -130,7 +130,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 {
     using G = Geom<AT>;
     constexpr int EPT = G::EPT, NP = G::NP;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & (kThreads - 1);   // (a 512-thread workgroup runs two 128-row halves side by side: fused_layer.hip, wide8)
     const int lane = tid & 63;
     const int s_k = (tid % G::TPR) * EPT;  // first k of this thread's 16-B piece
 

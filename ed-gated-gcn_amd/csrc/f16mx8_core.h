@@ -122,7 +122,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     using G = Geom<AT>;
     constexpr int EPT = G::EPT, NP = G::NP, NQ = EPT / 4;
     static_assert(BK == 32 && NP <= 4 && RN == 2, "the slot schedule below is written for BK = 32, <= 4 passes, RN = 2");
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & (kThreads - 1);
     const int lane = tid & 63;
     const int s_k = (tid % G::TPR) * EPT;
 

@@ -95,18 +95,27 @@ __device__ __forceinline__ float upper_half_to_lower(float v)
 }
 
 // 0/1 adjacency block as the MFMA A operand: bit b of `m` (already shifted by 4h) -> element pairs of the two
-// k-steps; element j of k-step s is node 16s + 8(j>>2) + 4h + (j&3)
+// k-steps; element j of k-step s is node 16s + 8(j>>2) + 4h + (j&3).  Per dword (two elements = two neighbouring bits):
+// both halves of a register hold the 16 mask bits of the k-step, a packed shift brings bit b + 1 / bit b to the top of
+// the high / low half, a packed arithmetic shift spreads them (0 or 0xFFFF) and one AND leaves bf16 1.0 = 0x3F80 --
+// three VALU per dword (+ one per k-step) where the scalar bit-field form took four.
 __device__ __forceinline__ void expand_mask(uint32_t mh, bf16x8 (&af)[2])
 {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
     union { bf16x8 v; uint32_t w[4]; } u[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+        const uint32_t m16 = s == 0 ? (mh & 0xFFFFu) : (mh >> 16);
+        const u16x2 both = __builtin_bit_cast(u16x2, m16 | (m16 << 16));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int b = 16 * s + 8 * (q >> 1) + 2 * (q & 1);
-            const uint32_t two = (mh >> b) & 3u;
-            u[s].w[q] = (two & 1u) * 0x3F80u + (two >> 1) * 0x3F800000u;  // bf16 1.0 = 0x3F80
+            const int b = 8 * (q >> 1) + 2 * (q & 1);
+            const u16x2 top = both << u16x2{(unsigned short)(15 - b), (unsigned short)(14 - b)};   // low half: bit b, high half: bit b + 1
+            const i16x2 spread = __builtin_bit_cast(i16x2, top) >> i16x2{15, 15};
+            u[s].w[q] = __builtin_bit_cast(uint32_t, spread) & 0x3F803F80u;
         }
+    }
     af[0] = u[0].v;
     af[1] = u[1].v;
 }
@@ -653,12 +662,11 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused6_kernel(c
 // with every hidden[ii] taken from the accumulator tiles as in the 32-node kernel.  All accumulators are first
 // split into their two bf16 planes IN PLACE (same register count), then each output block is produced,
 // normalised, gated, pooled and stored.  One part only (the two-layer block form stays with T <= 32).
-// SB = 8 (T in 129..256): the workgroup runs the main loop TWICE (rows 0-127, then 128-255 of its graph) and keeps
-// the first half's planes in registers meanwhile -- 256 registers of planes in the epilogue, so this variant is
-// built for one wavefront per SIMD (the 512-entry file: arch + accumulation registers) and the main loop runs at
-// its lone-wavefront speed: one launch and no [N,F] round trip of `hidden`, but measured 4-18 % SLOWER than
-// linear + aggregate at T = 231 (tools/wide_timing.py; skipping all-zero adjacency blocks made it slower still), so
-// the host side takes it only on request (GraphConvolution.fused_max_t = 256).
+// SB = 8 (T in 129..256), the FIRST form of the 256-row slot, kept behind GGCN_LAB_WIDE_SB8 for comparison: the workgroup
+// runs the main loop TWICE (rows 0-127, then 128-255 of its graph) and keeps the first half's planes in registers
+// meanwhile -- 256 registers of planes in the epilogue, so it is built for one wavefront per SIMD and the main loop runs
+// at its lone-wavefront speed: measured 4-18 % SLOWER than linear + aggregate at T = 231 (tools/wide_timing.py).  The
+// launcher takes layer_fused_wide8_kernel (below: eight wavefronts, both halves in flight) for these graphs.
 template <int SCH, bool AVEC, bool KFULL, bool VST, int SB>
 __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_fused_wide_kernel(const FusedArgs a)
 {
@@ -860,6 +868,266 @@ __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_f
     else graphs(std::false_type{});
 }
 
+// plain v_max / v_min (fmaxf first quiets a possible signalling NaN of its operands: an extra instruction per value)
+__device__ __forceinline__ float vmaxf_raw(float x, float y) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
+__device__ __forceinline__ float vminf_raw(float x, float y) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
+
+// ---- graphs of 129..256 nodes, two wavefronts per SIMD: EIGHT wavefronts per (graph, 256 columns) -----------------------
+// Wavefront (rg, cg) = rows 128 rg .. + 127 of the graph's 256-row slot x columns 64 cg .. + 63: the two row groups run
+// the SAME main loop side by side on their own stage buffers (thread ids taken mod 256 inside the loop), so the loop keeps
+// the two-wavefronts-per-SIMD speed of the 32-node kernel instead of the lone wavefront of the SB = 8 form above, and no
+// half of the graph waits in registers.  A neighbour sum needs hidden rows of BOTH row groups: per 32-column tile every
+// wavefront writes its bf16 plane fragments -- already in B-operand order -- to LDS (16 KiB each, over the dead stage
+// buffers), and every output block takes all 8 x 4 operand fragments from there.  160 KiB of LDS, one workgroup per CU.
+// Measured (tools/wide_timing.py, f16mx8, 512 x 231 x 768): 452 us against 496 us for linear + aggregate and 507 us for the
+// lone-wavefront form; parse-like graphs (arcs mostly short: empty adjacency blocks are skipped) 413-421 against 460-467.
+// Of the 452 us the main loop is 225 (timing build without the epilogue), the aggregation MFMAs ~100 and the rest of the
+// epilogue -- mask expansion (3 VALU per operand dword, 64 blocks per wavefront), normalise / gate / pool, stores -- ~125,
+// none of it under another workgroup's main loop: with one workgroup per CU the phases are serial, which is also why a
+// batch must fill whole rounds of 256 workgroups to win (GraphConvolution.takes_fused_path).
+constexpr int kW8Threads = 512;
+constexpr int kW8Ex = 8 * 16 * 1024;          // per wavefront: 4 row blocks x (2 planes x 2 k-steps) x 1 KiB
+constexpr int kW8Stage = 4096;                // per wavefront: 32 rows x 32 columns of output on their way to 16-byte stores
+constexpr int kW8Lds = kW8Ex + 8 * kW8Stage;  // 160 KiB
+static_assert(2 * kLdsBytes <= kW8Ex && kW8Lds <= 160 * 1024, "the stage buffers of both row groups lie under the exchange area");
+
+template <int SCH, bool AVEC, bool KFULL, bool VST>
+__global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds8[];
+    const int B = a.B, T = a.T, K = a.K, F = a.F;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.ov_in && blockIdx.x == 0) {   // reduce_partials with the first four wavefronts summing (same order, same result)
+        float *red = reinterpret_cast<float *>(lds8);
+        const int n_part = B * ((F + 63) / 64);
+        float sdot = 0.0f;
+        if (tid < kThreads)
+            for (int idx = tid; idx < n_part; idx += kThreads) sdot += a.ov_in[idx];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sdot += __shfl_xor(sdot, d);
+        if (lane == 0 && wave < 4) red[wave] = sdot;
+        __syncthreads();
+        if (tid == 0) *a.ov_out = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
+        __syncthreads();
+    }
+    int g, n_wgi;
+    if (!tile_of_block(blockIdx.x, a.g_tiles, a.n_wg, g, n_wgi)) return;   // one graph per workgroup: g_tiles = B
+    const LayerPart &lp = a.part[0];
+    const float *__restrict__ bias = lp.bias, *__restrict__ store_gate = lp.store_gate;
+    const float *__restrict__ pool_gate_a = lp.pool_gate_a, *__restrict__ pool_gate_b = lp.pool_gate_b;
+    float *__restrict__ out = lp.out, *__restrict__ pool_a = lp.pool_a, *__restrict__ pool_b = lp.pool_b;
+    const int ldo = lp.ldo;
+    const int rg = wave >> 2, cg = wave & 3;
+    const int n_tiles_total = (F + NT - 1) / NT;
+    const int nt0 = n_wgi * (BN / NT) + cg * RN;
+    const int W = (T + 31) >> 5;
+    static_assert(WM == 1 && RN == 2, "written for 128 x 64 wavefront tiles");
+
+    // ---- hidden = X . W for both row groups at once ----
+    constexpr int NP = Geom<float>::NP;
+    f32x16 acc[4][RN];
+    {
+        const float *arow[NP];
+        bool avalid[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int r = stage_row<float>(i) + 128 * rg;
+            avalid[i] = r < T;
+            arow[i] = a.X + ((int64_t)g * T + (avalid[i] ? r : 0)) * a.ldx;
+        }
+        char *stage = lds8 + rg * kLdsBytes;
+        if constexpr (SCH == 0)
+            bx3::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps, 0, nt0, n_tiles_total, stage, acc);
+        else
+            mx8::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc);
+    }
+    // every accumulator tile -> its two bf16 planes (B-operand fragments of the aggregation MFMAs), in place
+    bf16x8 hf[4][RN][2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) split2(acc[i][j], hf[i][j]);
+
+    const int c = lane & 31, h = lane >> 5;
+    float vb[RN], vsg[RN], vga[RN], vgb[RN];
+    bool col_ok[RN];
+    {
+        const float *dummy = a.X;
+        const float *pb = bias ? bias : dummy, *psg = store_gate ? store_gate : dummy;
+        const float *pga = pool_gate_a ? pool_gate_a : dummy, *pgb = pool_gate_b ? pool_gate_b : dummy;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const int gn = (nt0 + j) * NT + c;
+            col_ok[j] = gn < F;
+            const int gnc = col_ok[j] ? gn : 0;
+            const int64_t at = (int64_t)g * F + gnc;
+            vb[j] = bias ? pb[gnc] : 0.0f;
+            vsg[j] = store_gate ? psg[at] : 1.0f;
+            vga[j] = pool_gate_a ? pga[at] : 1.0f;
+            vgb[j] = pool_gate_b ? pgb[at] : 1.0f;
+        }
+    }
+    // this lane's adjacency rows of output block io (node 32 io + c), one block ahead of their use; words past the graph
+    // and rows past T read as zeros
+    auto load_masks = [&](int io, uint32_t (&m)[8]) {
+        const int node = 32 * io + c;
+        const bool ok = node < T;
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const bool okw = ok && ii < W;
+            const uint32_t v = a.rowmask[okw ? ((int64_t)g * T + node) * W + ii : 0];
+            m[ii] = okw ? v : 0u;
+        }
+    };
+    uint32_t mw[2][8];
+    load_masks(4 * rg, mw[0]);
+    float *stage_lds = reinterpret_cast<float *>(lds8 + kW8Ex + wave * kW8Stage);
+    const int perm_base = 16 * h;
+    const int lane_off = 4 * h * ldo + c;
+    float vmax[RN], vmin[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) { vmax[j] = -INFINITY; vmin[j] = INFINITY; }
+
+    auto tiles = [&](auto has_out) {
+        constexpr bool vst = VST && decltype(has_out)::value;
+        constexpr bool direct_store = !VST && decltype(has_out)::value;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            __syncthreads();   // the fragments of column tile j - 1 (j = 0: the last stage's operand planes) have been read
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        *reinterpret_cast<bf16x8 *>(lds8 + (((wave * 4 + i) * 2 + p) * 2 + ks) * 1024 + lane * 16) = hf[i][j][p][ks];
+            __syncthreads();
+            const bool tile_ok = nt0 + j < n_tiles_total;   // wavefront-uniform: column tile past F
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 4 * j + i, io = 4 * rg + i, node0 = 32 * io;
+                // the next block's masks (wraps to this wavefront's first block for the second column tile)
+                if (t + 1 < 4 * RN) load_masks(4 * rg + ((i + 1) & 3), mw[(t + 1) & 1]);
+                if (node0 >= T || !tile_ok) continue;   // wavefront-uniform: a block of padding rows (no barrier below)
+                const uint32_t (&m)[8] = mw[t & 1];
+                int deg = 0;
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) deg += __popc(m[ii]);
+                const float inv = 1.0f / (float)(deg + 1);                  // gcn.py:35
+                f32x16 y;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[r] = 0.0f;
+                // The four operand fragments of block ii + 1 are asked for before block ii's MFMAs (an empty block's are read in
+                // vain): read just in front of their use, every pair of MFMAs waited out an LDS round trip.
+                auto frag_src = [&](int ii) { return lds8 + ((((ii >> 2) * 4 + cg) * 4 + (ii & 3)) * 4) * 1024 + lane * 16; };
+                bf16x8 fr[2][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fr[0][q] = *reinterpret_cast<const bf16x8 *>(frag_src(0) + q * 1024);
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) {
+                    if (32 * ii >= T) break;   // workgroup-uniform: source blocks of padding rows
+                    if (ii + 1 < 8) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) fr[(ii + 1) & 1][q] = *reinterpret_cast<const bf16x8 *>(frag_src(ii + 1) + q * 1024);
+                    }
+                    // a block without an edge adds nothing (dependency arcs are mostly short: away from the diagonal most
+                    // blocks of a parse are empty); wavefront-uniform
+                    if (__builtin_amdgcn_ballot_w64(m[ii] != 0u) == 0) continue;
+                    bf16x8 af[2];
+                    expand_mask(m[ii] >> (4 * h), af);   // once per block: both planes use it (small plane first)
+#pragma unroll
+                    for (int p = 1; p >= 0; --p)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            if constexpr (!((GGCN_LAB_OFF) & 64))
+                                y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], fr[ii & 1][2 * p + ks], y, 0, 0, 0);   // gcn.py:41
+                }
+                float rinv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row0 = (r & 3) + 8 * (r >> 2);
+                    rinv[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_base + 4 * row0, __float_as_int(inv)));
+                }
+                float *tile = decltype(has_out)::value ? out + ((int64_t)g * T + node0) * ldo + (nt0 + j) * NT : nullptr;
+                auto finish = [&](auto whole_c) {   // whole: all 32 rows of the block are nodes (wavefront-uniform) -- no row test
+                    constexpr bool WHOLE = decltype(whole_c)::value;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
+                        const float v = y[r] * rinv[r] + vb[j];   // gcn.py:41,43
+                        if (vst) stage_lds[(row0 + 4 * h) * 32 + c] = v * vsg[j];
+                        if (WHOLE || node0 + row0 + 4 * h < T) {
+                            if (direct_store && col_ok[j]) tile[lane_off + row0 * ldo] = v * vsg[j];
+                            vmax[j] = vmaxf_raw(vmax[j], v);
+                            vmin[j] = vminf_raw(vmin[j], v);
+                        }
+                    }
+                };
+                if (node0 + 32 <= T) finish(std::true_type{});
+                else finish(std::false_type{});
+                if (vst) {   // 32 rows x 128 B leave as 16 B per lane: 8 rows per instruction
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int colq = (lane & 7) * 4;
+                    const int gcol = (nt0 + j) * NT + colq;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = 8 * it + (lane >> 3);
+                        const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 32 + colq]);
+                        if (node0 + row < T && gcol < F) *reinterpret_cast<float4 *>(tile + row * ldo + colq) = v4;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    };
+    if constexpr (!((GGCN_LAB_OFF) & 128)) {
+        if (out) tiles(std::true_type{});
+        else tiles(std::false_type{});
+    } else {
+        asm volatile("" :: "v"(hf[0][0][0][0]), "v"(hf[3][1][1][1]), "v"(hf[1][0][1][0]), "v"(hf[2][1][0][1]));
+    }
+
+    // pools of the graph: max over ALL its rows (bert_amir5.py:635-640) -- the two row groups meet in LDS
+    if (pool_a || pool_b || lp.ov_partial) {
+        float *pl = reinterpret_cast<float *>(lds8 + kW8Ex);   // [wavefront][max / min][column tile][32] over the store staging
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const float mx = fmaxf(vmax[j], upper_half_to_lower(vmax[j]));
+            const float mn = fminf(vmin[j], upper_half_to_lower(vmin[j]));
+            if (h == 0) {
+                pl[((wave * 2 + 0) * RN + j) * 32 + c] = mx;
+                pl[((wave * 2 + 1) * RN + j) * 32 + c] = mn;
+            }
+        }
+        __syncthreads();
+        if (rg == 0) {
+            float dot = 0.0f;
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                if (nt0 + j >= n_tiles_total) break;
+                const float mx = fmaxf(pl[((wave * 2 + 0) * RN + j) * 32 + c], pl[(((wave + 4) * 2 + 0) * RN + j) * 32 + c]);
+                const float mn = fminf(pl[((wave * 2 + 1) * RN + j) * 32 + c], pl[(((wave + 4) * 2 + 1) * RN + j) * 32 + c]);
+                if (h == 0 && col_ok[j]) {
+                    const int gn = (nt0 + j) * NT + c;
+                    const float pa = vga[j] * (vga[j] >= 0.0f ? mx : mn), pb = vgb[j] * (vgb[j] >= 0.0f ? mx : mn);
+                    if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
+                    if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
+                    dot = fmaf(pa, pb, dot);
+                }
+            }
+            if (lp.ov_partial && nt0 < n_tiles_total) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
+                if (lane == 0) lp.ov_partial[(int64_t)g * ((F + 63) / 64) + (nt0 >> 1)] = dot;
+            }
+        }
+    }
+}
+
 // bert_amir5.py:638 after ggcn_block_fused: the per-(graph, 64-column group) partials -> one scalar.
 // One workgroup of 1024 threads, 16-byte loads with four independent sums per thread (config 2: 196 KB in
 // ~3 us; the 256-thread scalar loop took 67 us), fixed summation order: deterministic.
@@ -977,6 +1245,27 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
         else if (fast) GGCN_LAUNCHW(SC, true, true, false, SBV);         \
         else GGCN_LAUNCHW(SC, false, false, false, SBV);                 \
     } while (0)
+        if (sb == 8 && !GGCN_LAB_WIDE_SB8) {   // 129..256 nodes: eight wavefronts per graph (layer_fused_wide8_kernel)
+#define GGCN_LAUNCH8(SC, AV, KF, VS)                                                                                      \
+    do {                                                                                                                  \
+        auto kern = layer_fused_wide8_kernel<SC, AV, KF, VS>;                                                             \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                kW8Lds) != hipSuccess)                                                                    \
+            return fail(GGCN_ELAUNCH, "%s: cannot reserve %d bytes of LDS", who, kW8Lds);                                 \
+        hipLaunchKernelGGL(kern, dim3((unsigned)gridw), dim3(kW8Threads), kW8Lds, st, a);                                 \
+    } while (0)
+#define GGCN_PICK8(SC)                                      \
+    do {                                                    \
+        if (fast && vst) GGCN_LAUNCH8(SC, true, true, true);        \
+        else if (fast) GGCN_LAUNCH8(SC, true, true, false);         \
+        else GGCN_LAUNCH8(SC, false, false, false);                 \
+    } while (0)
+            if (precision == GGCN_PREC_F16MX8) GGCN_PICK8(1);
+            else GGCN_PICK8(0);
+#undef GGCN_PICK8
+#undef GGCN_LAUNCH8
+            return check_launch(who);
+        }
         if (precision == GGCN_PREC_F16MX8) { if (sb == 2) GGCN_PICKW(1, 2); else if (sb == 4) GGCN_PICKW(1, 4); else GGCN_PICKW(1, 8); }
         else { if (sb == 2) GGCN_PICKW(0, 2); else if (sb == 4) GGCN_PICKW(0, 4); else GGCN_PICKW(0, 8); }
 #undef GGCN_PICKW

@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ed_gated_gcn_amd as pkg
 from ed_gated_gcn_amd import synth
 dev = torch.device("cuda:0")
-SHAPES = ((256, 100, 256), (1024, 100, 768), (2048, 64, 768), (1024, 128, 768), (256, 231, 256), (64, 231, 768), (512, 231, 768), (512, 256, 768))
+if os.environ.get("LAB_SHAPES"):   # e.g. LAB_SHAPES="512,231,768;512,256,768"
+    SHAPES = tuple(tuple(int(v) for v in t.split(",")) for t in os.environ["LAB_SHAPES"].split(";"))
+else:
+  SHAPES = ((256, 100, 256), (1024, 100, 768), (2048, 64, 768), (1024, 128, 768), (256, 231, 256), (64, 231, 768), (512, 231, 768), (512, 256, 768))
 import numpy as np
 def local_batch(B, T, span=6, seed=3):
     """Parse-like arcs: every token's head lies within `span` tokens (most real dependency arcs are short), one long arc
@@ -28,7 +31,7 @@ for case in SHAPES + tuple(c + ("local",) for c in SHAPES if c[1] > 128):
     g1 = torch.rand(B, H, device=dev); g2 = torch.rand(B, H, device=dev)
     w, b = synth.layer_params(H, H, seed=1)
     res = {}
-    for prec in ("f16mx8", "bf16x3"):
+    for prec in os.environ.get("LAB_PRECS", "f16mx8,bf16x3").split(","):
         for fused in (True, False):
             m = pkg.GraphConvolution(H, H, None).to(dev); m.precision = prec; m.fused = fused; m.fused_max_t = 256
             with torch.no_grad():
