@@ -87,6 +87,17 @@ __device__ __forceinline__ void split2(const f32x16 &acc, bf16x8 (&frag)[2][2])
         }
 }
 
+// the [N,F] output leaves in 16-byte pieces; GGCN_LAB_NT_STORE (lab_hooks.h) makes them non-temporal
+__device__ __forceinline__ void store_out4(float *p, const float4 &v)
+{
+#if GGCN_LAB_NT_STORE
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4 *>(p));
+#else
+    *reinterpret_cast<float4 *>(p) = v;
+#endif
+}
+
 // lanes 0-31 receive the value of lane + 32 (lanes 32-63: unspecified, their own lower-half partner's value)
 __device__ __forceinline__ float upper_half_to_lower(float v)
 {
@@ -480,7 +491,7 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
             for (int it = 0; it < 8; ++it) {
                 const int row = 4 * it + (lane >> 4);
                 const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 64 + (colq ^ (32 * ((row >> 2) & 1)))]);
-                if ((FULLT || row < T) && gcol < F) *reinterpret_cast<float4 *>(gbase + row * ldo) = v4;
+                if ((FULLT || row < T) && gcol < F) store_out4(gbase + row * ldo, v4);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -835,7 +846,7 @@ __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_f
                     for (int it = 0; it < 8; ++it) {
                         const int row = 4 * it + (lane >> 4);
                         const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 64 + (colq ^ (32 * ((row >> 2) & 1)))]);
-                        if (node0 + row < T && gcol < F) *reinterpret_cast<float4 *>(gbase + row * ldo) = v4;
+                        if (node0 + row < T && gcol < F) store_out4(gbase + row * ldo, v4);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -1035,6 +1046,11 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                     // blocks of a parse are empty); wavefront-uniform
                     if (__builtin_amdgcn_ballot_w64(m[ii] != 0u) == 0) continue;
                     bf16x8 af[2];
+                    if constexpr (((GGCN_LAB_OFF) & 32) != 0) {   // (timing build: no expansion)
+                        union { bf16x8 v; uint32_t w[4]; } u;
+                        u.w[0] = u.w[1] = u.w[2] = u.w[3] = m[ii] & 0x3F803F80u;
+                        af[0] = af[1] = u.v;
+                    } else
                     expand_mask(m[ii] >> (4 * h), af);   // once per block: both planes use it (small plane first)
 #pragma unroll
                     for (int p = 1; p >= 0; --p)
@@ -1064,6 +1080,10 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                         }
                     }
                 };
+                if constexpr (((GGCN_LAB_OFF) & 16) != 0) {   // (timing build: nothing behind the neighbour sums)
+                    asm volatile("" :: "v"(y[0]), "v"(y[5]), "v"(y[10]), "v"(y[15]), "v"(rinv[3]));
+                    continue;
+                }
                 if (node0 + 32 <= T) finish(std::true_type{});
                 else finish(std::false_type{});
                 if (vst) {   // 32 rows x 128 B leave as 16 B per lane: 8 rows per instruction
@@ -1075,7 +1095,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                     for (int it = 0; it < 4; ++it) {
                         const int row = 8 * it + (lane >> 3);
                         const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 32 + colq]);
-                        if (node0 + row < T && gcol < F) *reinterpret_cast<float4 *>(tile + row * ldo + colq) = v4;
+                        if (node0 + row < T && gcol < F) store_out4(tile + row * ldo + colq, v4);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     __builtin_amdgcn_wave_barrier();

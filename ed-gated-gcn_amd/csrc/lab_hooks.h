@@ -16,6 +16,9 @@
 // timing-only elimination ladder of the f16mx8 main loop (bit set = that step is switched off; wrong results):
 // 1 X global loads, 2 split VALU, 4 LDS plane writes, 8 LDS fragment reads, 16 W loads, 32 wh8 converts, 64 barrier,
 // 128 epilogue (fused_layer.hip)
+#ifndef GGCN_LAB_NT_STORE
+#define GGCN_LAB_NT_STORE 0     // 1: the one-launch kernels store the [N,F] output with the non-temporal hint
+#endif
 #ifndef GGCN_LAB_WIDE_SB8
 #define GGCN_LAB_WIDE_SB8 0   // 1: graphs of 129..256 nodes through the older lone-wavefront form (layer_fused_wide_kernel<.., 8>)
 #endif
