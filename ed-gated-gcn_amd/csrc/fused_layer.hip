@@ -898,6 +898,7 @@ __device__ __forceinline__ float vminf_raw(float x, float y) { float d; asm("v_m
 // batch must fill whole rounds of 256 workgroups to win (GraphConvolution.takes_fused_path).
 constexpr int kW8Threads = 512;
 constexpr int kW8Ex = 8 * 16 * 1024;          // per wavefront: 4 row blocks x (2 planes x 2 k-steps) x 1 KiB
+constexpr int kW8Cap = 16;                   // source ids per row kept in LDS (rows with more neighbours walk their mask words)
 constexpr int kW8Stage = 4096;                // per wavefront: 32 rows x 32 columns of output on their way to 16-byte stores
 constexpr int kW8Lds = kW8Ex + 8 * kW8Stage;  // 160 KiB
 static_assert(2 * kLdsBytes <= kW8Ex && kW8Lds <= 160 * 1024, "the stage buffers of both row groups lie under the exchange area");
@@ -953,6 +954,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
         else
             mx8::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc);
     }
+    if constexpr (GGCN_LAB_WIDE8_DENSE) {
     // every accumulator tile -> its two bf16 planes (B-operand fragments of the aggregation MFMAs), in place
     bf16x8 hf[4][RN][2][2];
 #pragma unroll
@@ -1145,6 +1147,183 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                 if (lane == 0) lp.ov_partial[(int64_t)g * ((F + 63) / 64) + (nt0 >> 1)] = dot;
             }
         }
+    }
+
+    } else {
+    // ---- neighbour sums over the EDGES, out of an fp32 tile in LDS (gcn.py:41) ----------------------------------------
+    // Per 32-column tile j every wavefront writes its accumulators, as they are, into its column group's tile
+    // [256 rows][32 columns] fp32 (4 x 32 KiB over the dead stage buffers).  Then 8 lanes x 16 B cover a row: a wavefront
+    // sums 8 destination rows at once, each 8-lane group reading its row's edge list (up to kW8Cap source ids, made once
+    // per workgroup from the row masks: ids and degrees in LDS) and then the source rows' 16-byte pieces, 8 in flight --
+    // two dependent LDS round trips per 8 edges, ~5 reads and 20 adds per row of a parse, instead of 8 blocks x 4 MFMAs and
+    // the expansion of 8 mask words into MFMA operands.  The sums are exact fp32; rows leave straight from registers as
+    // 16-byte stores.  (A first form that walked the mask bits one LDS read at a time took 630 us where the MFMA form
+    // took 470: every edge waited out its own round trip.)
+    const int q8 = lane >> 3, cl = lane & 7;
+    const int c = lane & 31, h = lane >> 5;
+    char *tile_cg = lds8 + cg * (256 * 128);
+    unsigned short *s_ids = reinterpret_cast<unsigned short *>(lds8 + kW8Ex + 4096);   // [256 rows][kW8Cap]
+    int *s_deg = reinterpret_cast<int *>(lds8 + kW8Ex + 4096 + 256 * kW8Cap * 2);      // [256]
+    float *s_inv = reinterpret_cast<float *>(lds8 + kW8Ex + 4096 + 256 * kW8Cap * 2 + 1024);   // [256] 1 / (deg + 1)
+    const int zero_off = kW8Ex + 4096 + 256 * kW8Cap * 2 + 2048;                         // 128 B of zeros
+    // 16-byte chunk `chunk` of row `row`: the 64-byte half is flipped on rows 2, 3 (mod 4), so that the four 8-lane groups a
+    // ds_read_b128 serves together (two read chunks 0-3, two chunks 4-7 of their rows) collide on one row pair in four
+    auto tile_off = [](int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); };
+    // edge lists of the graph's rows, once per workgroup (thread t < 256: row t)
+    if (tid < 256) {
+        const int row = tid;
+        uint32_t mwd[8];
+#pragma unroll
+        for (int wi = 0; wi < 8; ++wi) {
+            const bool ok = row < T && wi < W;
+            const uint32_t v = a.rowmask[ok ? ((int64_t)g * T + row) * W + wi : 0];
+            mwd[wi] = ok ? v : 0u;
+        }
+        int deg = 0, e = 0;
+#pragma unroll
+        for (int wi = 0; wi < 8; ++wi) {
+            uint32_t w = mwd[wi];
+            deg += __popc(w);
+            while (w && e < kW8Cap) {   // stored: the source row's byte offset in a tile (chunk 0; a lane XORs its 16 cl in)
+                s_ids[row * kW8Cap + e++] = (unsigned short)tile_off(32 * wi + __builtin_ctz(w), 0);
+                w &= w - 1;
+            }
+        }
+        s_deg[row] = deg;
+        s_inv[row] = 1.0f / (float)(deg + 1);                               // gcn.py:35
+        if (tid < 32) reinterpret_cast<float *>(lds8 + zero_off)[tid] = 0.0f;
+    }
+    float vmax[RN][4], vmin[RN][4];
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { vmax[j][k] = -INFINITY; vmin[j][k] = INFINITY; }
+    const float *dummy = a.X;
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        __syncthreads();   // the tile of column tile j - 1 (j = 0: the last stage's operand planes) has been read
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 128 * rg + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                *reinterpret_cast<float *>(tile_cg + tile_off(row, c >> 2) + (c & 3) * 4) = acc[i][j][r];
+            }
+        __syncthreads();   // (also: the edge lists are complete)
+        if (nt0 + j >= n_tiles_total) continue;   // wavefront-uniform: column tile past F (the barriers above are met)
+        const int col0 = (nt0 + j) * NT + 4 * cl;   // this lane's four columns
+        float b4[4], sg4[4];
+        bool cok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cok[k] = col0 + k < F;
+            const int cc = cok[k] ? col0 + k : 0;
+            b4[k] = bias ? (bias ? bias : dummy)[cc] : 0.0f;
+            sg4[k] = store_gate ? (store_gate ? store_gate : dummy)[(int64_t)g * F + cc] : 1.0f;
+        }
+        const int tile_lane = cg * (256 * 128) + 16 * cl, zero_lane = zero_off + 16 * cl;
+        for (int it = 0; it < 16; ++it) {
+            if (128 * rg + 8 * it >= T) break;   // wavefront-uniform: only padding rows from here on
+            const int row = 128 * rg + 8 * it + q8;
+            const int deg = s_deg[row];
+            const float inv = s_inv[row];
+            float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (deg <= kW8Cap) {
+                for (int e0 = 0; e0 < deg; e0 += 8) {   // (rows differ per 8-lane group: plain divergent control flow)
+                    const uint4 idq = *reinterpret_cast<const uint4 *>(s_ids + row * kW8Cap + e0);
+                    const uint32_t idw[4] = {idq.x, idq.y, idq.z, idq.w};
+                    float4 v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int base = (int)((idw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                        const int off = e0 + e < deg ? tile_lane ^ base : zero_lane;   // (base has no bits below 64; tile_lane = cg base + 16 cl)
+                        v[e] = *reinterpret_cast<const float4 *>(lds8 + off);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s4[0] += v[e].x; s4[1] += v[e].y; s4[2] += v[e].z; s4[3] += v[e].w; }
+                }
+            } else {   // more neighbours than a list holds: walk the mask words themselves (rare, slow, same sums in another order)
+                for (int wi = 0; wi < W; ++wi) {
+                    uint32_t w = a.rowmask[((int64_t)g * T + row) * W + wi];
+                    while (w) {
+                        const int src = 32 * wi + __builtin_ctz(w);
+                        w &= w - 1;
+                        const float4 v = *reinterpret_cast<const float4 *>(tile_cg + tile_off(src, cl));
+                        s4[0] += v.x; s4[1] += v.y; s4[2] += v.z; s4[3] += v.w;
+                    }
+                }
+            }
+            if (row < T) {
+                float o4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = s4[k] * inv + b4[k];                    // gcn.py:41,43
+                    o4[k] = v * sg4[k];
+                    vmax[j][k] = vmaxf_raw(vmax[j][k], v);
+                    vmin[j][k] = vminf_raw(vmin[j][k], v);
+                }
+                if (out) {
+                    float *dst = out + ((int64_t)g * T + row) * ldo + col0;
+                    if constexpr (VST) {
+                        if (cok[0]) store_out4(dst, make_float4(o4[0], o4[1], o4[2], o4[3]));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (cok[k]) dst[k] = o4[k];
+                    }
+                }
+            }
+        }
+    }
+    // pools of the graph: max over ALL its rows (bert_amir5.py:635-640): across the 8 row classes of the wavefront (lanes 8
+    // apart), then the two row groups meet in LDS
+    if (pool_a || pool_b || lp.ov_partial) {
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int d = 8; d <= 32; d <<= 1) {
+                    vmax[j][k] = vmaxf_raw(vmax[j][k], __shfl_xor(vmax[j][k], d));
+                    vmin[j][k] = vminf_raw(vmin[j][k], __shfl_xor(vmin[j][k], d));
+                }
+        float *pl = reinterpret_cast<float *>(lds8 + kW8Ex);   // [wavefront][max / min][column tile][32]
+        __syncthreads();
+        if (q8 == 0) {
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pl[((wave * 2 + 0) * RN + j) * 32 + 4 * cl + k] = vmax[j][k];
+                    pl[((wave * 2 + 1) * RN + j) * 32 + 4 * cl + k] = vmin[j][k];
+                }
+        }
+        __syncthreads();
+        if (rg == 0) {
+            float dot = 0.0f;
+            if (lane < 32) {
+#pragma unroll
+                for (int j = 0; j < RN; ++j) {
+                    const int gn = (nt0 + j) * NT + lane;
+                    if (nt0 + j < n_tiles_total && gn < F) {
+                        const float mx = fmaxf(pl[((wave * 2 + 0) * RN + j) * 32 + lane], pl[(((wave + 4) * 2 + 0) * RN + j) * 32 + lane]);
+                        const float mn = fminf(pl[((wave * 2 + 1) * RN + j) * 32 + lane], pl[(((wave + 4) * 2 + 1) * RN + j) * 32 + lane]);
+                        const float ga = pool_gate_a ? pool_gate_a[(int64_t)g * F + gn] : 1.0f;
+                        const float gb = pool_gate_b ? pool_gate_b[(int64_t)g * F + gn] : 1.0f;
+                        const float pa = ga * (ga >= 0.0f ? mx : mn), pb = gb * (gb >= 0.0f ? mx : mn);
+                        if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
+                        if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
+                        dot = fmaf(pa, pb, dot);
+                    }
+                }
+            }
+            if (lp.ov_partial && nt0 < n_tiles_total) {   // fixed butterfly order; lanes 32-63 hold 0
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
+                if (lane == 0) lp.ov_partial[(int64_t)g * ((F + 63) / 64) + (nt0 >> 1)] = dot;
+            }
+        }
+    }
     }
 }
 

@@ -19,6 +19,9 @@
 #ifndef GGCN_LAB_NT_STORE
 #define GGCN_LAB_NT_STORE 0     // 1: the one-launch kernels store the [N,F] output with the non-temporal hint
 #endif
+#ifndef GGCN_LAB_WIDE8_DENSE
+#define GGCN_LAB_WIDE8_DENSE 0   // 1: layer_fused_wide8_kernel aggregates with dense 32 x 32 adjacency blocks on the MFMAs (its first form)
+#endif
 #ifndef GGCN_LAB_WIDE_SB8
 #define GGCN_LAB_WIDE_SB8 0   // 1: graphs of 129..256 nodes through the older lone-wavefront form (layer_fused_wide_kernel<.., 8>)
 #endif
