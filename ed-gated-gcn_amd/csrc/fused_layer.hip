@@ -887,15 +887,15 @@ __device__ __forceinline__ float vminf_raw(float x, float y) { float d; asm("v_m
 // Wavefront (rg, cg) = rows 128 rg .. + 127 of the graph's 256-row slot x columns 64 cg .. + 63: the two row groups run
 // the SAME main loop side by side on their own stage buffers (thread ids taken mod 256 inside the loop), so the loop keeps
 // the two-wavefronts-per-SIMD speed of the 32-node kernel instead of the lone wavefront of the SB = 8 form above, and no
-// half of the graph waits in registers.  A neighbour sum needs hidden rows of BOTH row groups: per 32-column tile every
-// wavefront writes its bf16 plane fragments -- already in B-operand order -- to LDS (16 KiB each, over the dead stage
-// buffers), and every output block takes all 8 x 4 operand fragments from there.  160 KiB of LDS, one workgroup per CU.
-// Measured (tools/wide_timing.py, f16mx8, 512 x 231 x 768): 452 us against 496 us for linear + aggregate and 507 us for the
-// lone-wavefront form; parse-like graphs (arcs mostly short: empty adjacency blocks are skipped) 413-421 against 460-467.
-// Of the 452 us the main loop is 225 (timing build without the epilogue), the aggregation MFMAs ~100 and the rest of the
-// epilogue -- mask expansion (3 VALU per operand dword, 64 blocks per wavefront), normalise / gate / pool, stores -- ~125,
-// none of it under another workgroup's main loop: with one workgroup per CU the phases are serial, which is also why a
-// batch must fill whole rounds of 256 workgroups to win (GraphConvolution.takes_fused_path).
+// half of the graph waits in registers.  A neighbour sum needs hidden rows of BOTH row groups, so the accumulators go to
+// LDS per 32-column tile -- as an fp32 tile [256 rows][32 columns] per column group, 128 KiB over the dead stage buffers --
+// and the sums run over per-row EDGE LISTS (made once per workgroup from the row masks) with 8 lanes x 16 B per row, 8
+// source rows in flight: exact fp32 sums, ~5 LDS reads + 20 adds per row of a parse.  160 KiB of LDS, one workgroup per CU.
+// Measured (tools/wide_timing.py, f16mx8, 512 x 231 x 768): 399 us against 498 us for linear + aggregate (507 us for the
+// lone-wavefront form); 228 us of it is the main loop (timing build without the epilogue), the rest runs under nothing:
+// with one workgroup per CU the phases are serial.  The FIRST form of this epilogue (GGCN_LAB_WIDE8_DENSE: bf16 plane
+// fragments exchanged through LDS, dense 32 x 32 adjacency blocks on the MFMAs, mask words expanded into operands, empty
+// blocks skipped) took 456 us: 8 x 4 MFMAs and ~100 VALU of expansion per block against a handful of edges per row.
 constexpr int kW8Threads = 512;
 constexpr int kW8Ex = 8 * 16 * 1024;          // per wavefront: 4 row blocks x (2 planes x 2 k-steps) x 1 KiB
 constexpr int kW8Cap = 16;                   // source ids per row kept in LDS (rows with more neighbours walk their mask words)

@@ -153,8 +153,8 @@ class GraphConvolution(nn.Module):
         # GGCN_PRECISION, for activations of ordinary magnitude (validate_range() checks a batch).
         self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "bf16x3")
         # one-launch layer (fused_layer.hip) when the batch allows it: T <= fused_max_t, binary adjacency, split
-        # precision.  128 by default; graphs of 200..256 nodes (ACE cased's ORI_ML = 231) take the eight-wavefront
-        # form on their own when the batch fills the chip (takes_fused_path); set 256 to take it always.
+        # precision.  128 by default; graphs of 193..256 nodes (ACE cased's ORI_ML = 231) take the eight-wavefront
+        # form on their own (takes_fused_path); set 256 to send graphs of 129..192 nodes there as well.
         self.fused = bool(getattr(opt, "ggcn_fused", True)) and os.environ.get("GGCN_FUSED", "1") != "0"
         self.fused_max_t = int(getattr(opt, "ggcn_fused_max_t", None) or os.environ.get("GGCN_FUSED_MAX_T", "128"))
         # dense adjacency handed to forward(): None = let the device detect edge weights (one 4-byte
@@ -292,27 +292,22 @@ class GraphConvolution(nn.Module):
                                             or (self.bias is not None and self.bias.requires_grad)
                                             or any(g is not None and g.requires_grad for g in gates))
 
-    WIDE_AUTO_MIN_T = 200     # graphs of 200..256 nodes fill >= 78 % of the 256-row slot of the eight-wavefront kernel
-    WIDE_AUTO_FILL = 0.9      # ... and the workgroups (one per CU at a time) must fill their last round this far
+    WIDE_AUTO_MIN_T = 193     # graphs of 193..256 nodes fill >= 75 % of the 256-row slot of the eight-wavefront kernel
 
     def takes_fused_path(self, text, csr):
         """True when ``forward_gated`` will run as ONE launch (``ggcn_layer_fused``): graphs of <= ``fused_max_t``
         nodes (row masks exist up to 256), 0/1 adjacency, float32 features, a split-precision linear.  Beyond
-        ``fused_max_t`` (128 by default), graphs of 200..256 nodes (ACE cased: ``ORI_ML = 231``, ``constant.py:267``) still
-        take it when the batch is large enough for the eight-wavefront form (one workgroup per CU and graph x 256
-        columns) to win over linear + aggregate: at least two rounds of workgroups with the last round >= 90 % full
-        (512 x 231 x 768: 452 vs 496 us; 192 x 231 x 768, 2.25 rounds: 230 vs 202 us -- ``tools/wide_timing.py``)."""
+        ``fused_max_t`` (128 by default), graphs of 193..256 nodes (ACE cased: ``ORI_ML = 231``, ``constant.py:267``) take
+        the eight-wavefront form (``layer_fused_wide8_kernel``: one workgroup per graph x 256 columns) on their own: it
+        wins over linear + aggregate by 20 % on large batches (512 x 231 x 768: 399 vs 498 us) and ties on small or ragged
+        ones (128 x 231 x 768: 132 vs 132 us); graphs of 129..192 nodes leave too much of the 256-row slot empty
+        (512 x 160 x 768: 390 vs 356 us) and keep the two launches (``tools/wide_timing.py``)."""
         if not (self.fused and self.precision in _capi.PACKED and csr.rowmask is not None and csr.is_binary
                 and text.dtype == torch.float32):
             return False
         if csr.T <= self.fused_max_t:
             return True
-        if not (self.fused_max_t >= 128 and self.WIDE_AUTO_MIN_T <= csr.T <= 256 and text.is_cuda):
-            return False
-        wgs = text.shape[0] * ((self.out_features + 255) // 256)
-        cus = torch.cuda.get_device_properties(text.device).multi_processor_count
-        rounds = -(-wgs // cus)
-        return rounds >= 2 and wgs >= self.WIDE_AUTO_FILL * rounds * cus
+        return self.fused_max_t >= 128 and self.WIDE_AUTO_MIN_T <= csr.T <= 256
 
     LONG_MAX_T = 512   # include/ggcn.h GGCN_LONG_MAX_T
 

@@ -1578,11 +1578,10 @@ def test_wide_graph_layer_one_launch_vs_oracle(pkg, dev, precision, B, T, K, F, 
     assert pools_only[0] is None and torch.equal(pools_only[1], got[1]) and torch.equal(pools_only[2], got[2])
 
 
-def test_ace_length_graphs_take_the_eight_wavefront_layer_when_the_batch_fills_the_chip(pkg, dev):
-    """Graphs of 200..256 nodes (ACE cased, ORI_ML = 231: constant.py:267) go through the one-launch layer on their own --
-    no fused_max_t set -- when the workgroups (graph x 256 columns, one per CU) make >= 2 rounds with the last one >= 90 %
-    full; smaller or ragged batches, and graphs that would leave the 256-row slot mostly empty, keep linear + aggregate.
-    Both paths give the oracle's numbers."""
+def test_ace_length_graphs_take_the_eight_wavefront_layer(pkg, dev):
+    """Graphs of 193..256 nodes (ACE cased, ORI_ML = 231: constant.py:267) go through the one-launch layer on their own --
+    no fused_max_t set; graphs that would leave the 256-row slot mostly empty (129..192 nodes) keep linear + aggregate.
+    Both paths give the oracle's numbers; a row with more neighbours than an edge list holds (16) walks its mask words."""
     from ed_gated_gcn_amd import synth
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     H = 256
@@ -1592,17 +1591,27 @@ def test_ace_length_graphs_take_the_eight_wavefront_layer_when_the_batch_fills_t
     assert m.fused_max_t == 128
     with torch.no_grad():
         m.weight.copy_(torch.from_numpy(w)); m.bias.copy_(torch.from_numpy(b))
-    def csr_of(B, T):
-        adj = synth.dependency_batch(B, T, 4.0, seed=T)
+    def csr_of(B, T, degree=4.0):
+        adj = synth.dependency_batch(B, T, degree, seed=T)
         rp, ci, _ = synth.csr_from_dense_host(adj)
         return adj, pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
     took = {}
-    for B, T in ((2 * cus, 231), (2 * cus, 160), (2 * cus - cus // 2, 231), (cus // 2, 231), (2 * cus, 100)):
+    for B, T in ((2 * cus, 231), (8, 231), (8, 193), (8, 192), (8, 160), (8, 129), (8, 100)):
         adj, csr = csr_of(B, T)
-        x = torch.randn(B, T, H, device=dev) if (B, T) != (2 * cus, 231) else None
-        took[(B, T)] = m.takes_fused_path(torch.empty(B, T, H, device=dev) if x is None else x, csr)
-    assert took[(2 * cus, 231)] and took[(2 * cus, 100)]
-    assert not took[(2 * cus, 160)] and not took[(2 * cus - cus // 2, 231)] and not took[(cus // 2, 231)]
+        took[(B, T)] = m.takes_fused_path(torch.empty(B, T, H, device=dev), csr)
+    assert took[(2 * cus, 231)] and took[(8, 231)] and took[(8, 193)] and took[(8, 100)]
+    assert not took[(8, 192)] and not took[(8, 160)] and not took[(8, 129)]
+    # dense rows (> 16 neighbours: the mask-word walk) in a small batch
+    adj, csr = csr_of(6, 231, degree=24.0)
+    rng = np.random.default_rng(7)
+    x = torch.from_numpy(rng.standard_normal((6, 231, H)).astype(np.float32))
+    with torch.no_grad():
+        out, pa, _ = m.forward_gated(x.to(dev), csr, want_pool_a=True)
+    ref = ref_dense.graph_convolution(x, torch.from_numpy(adj.astype(np.float32)), torch.from_numpy(w), torch.from_numpy(b))
+    scale = max(1.0, float(ref.abs().max()))
+    assert int(adj.sum(-1).max()) > 16
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=TOL["f16mx8"] * scale)
+    np.testing.assert_allclose(pa.cpu().numpy(), ref.max(dim=1)[0].numpy(), rtol=0, atol=TOL["f16mx8"] * scale)
     # numbers: the auto-selected launch against the oracle on a slice of the big batch
     B, T = 2 * cus, 231
     adj, csr = csr_of(B, T)
