@@ -255,6 +255,9 @@ int ggcn_layer_fused_h(const void *X, int64_t ldx, const void *wpack,
  * NULL); precision is GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8.  T <= 32: one 32x32
  * accumulator tile is one graph.  32 < T <= 128: a graph takes a 64- or 128-row slot of a wavefront's tile and
  * its adjacency is applied as ceil(T/32)^2 blocks of 32x32 bits (LitBank: ORI_ML = 100, constant.py:227).
+ * 128 < T <= 256 (ACE cased: ORI_ML = 231, constant.py:267): eight wavefronts per graph; the accumulators of a
+ * 32-column tile go to an fp32 tile in LDS and the neighbour sums run over per-row edge lists made from the
+ * row masks (exact fp32 sums).
  * The gate-diversity regulariser (models/bert_amir5.py:638) can ride along instead of taking
  * ggcn_gate_overlap's two launches: overlap_partial (NULL or float[B * ceil(F/64)]) receives, per graph
  * and 64-column group, sum_f pool_a[g,f]*pool_b[g,f] of THIS launch (layer 1: x1.y1); overlap_in /
