@@ -535,7 +535,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
     const char *__restrict__ wpack = lp.wpack;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int gt0 = g_tile * (4 * WM);  // graph slots of 32 rows in this workgroup's tile
