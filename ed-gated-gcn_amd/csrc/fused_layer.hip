@@ -898,6 +898,10 @@ __device__ __forceinline__ float vminf_raw(float x, float y) { float d; asm("v_m
 constexpr int kW8Threads = 512;
 constexpr int kW8Ex = 8 * 16 * 1024;          // per wavefront: 4 row blocks x (2 planes x 2 k-steps) x 1 KiB
 constexpr int kW8Cap = 16;                   // source ids per row kept in LDS (rows with more neighbours walk their mask words)
+#ifndef GGCN_LAB_W8_SLOTS
+#define GGCN_LAB_W8_SLOTS 8
+#endif
+constexpr int kW8Slots = GGCN_LAB_W8_SLOTS;   // source rows in flight per pass over a row's edge list
 constexpr int kW8Stage = 4096;                // per wavefront: 32 rows x 32 columns of output on their way to 16-byte stores
 constexpr int kW8Lds = kW8Ex + 8 * kW8Stage;  // 160 KiB
 static_assert(2 * kLdsBytes <= kW8Ex && kW8Lds <= 160 * 1024, "the stage buffers of both row groups lie under the exchange area");
@@ -1228,18 +1232,24 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
             const float inv = s_inv[row];
             float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (deg <= kW8Cap) {
-                for (int e0 = 0; e0 < deg; e0 += 8) {   // (rows differ per 8-lane group: plain divergent control flow)
-                    const uint4 idq = *reinterpret_cast<const uint4 *>(s_ids + row * kW8Cap + e0);
-                    const uint32_t idw[4] = {idq.x, idq.y, idq.z, idq.w};
-                    float4 v[8];
+                for (int e0 = 0; e0 < deg; e0 += kW8Slots) {   // (rows differ per 8-lane group: plain divergent control flow)
+                    uint32_t idw[kW8Slots / 2];
+                    if constexpr (kW8Slots == 8) {
+                        const uint4 idq = *reinterpret_cast<const uint4 *>(s_ids + row * kW8Cap + e0);
+                        idw[0] = idq.x; idw[1] = idq.y; idw[kW8Slots / 2 - 2] = idq.z; idw[kW8Slots / 2 - 1] = idq.w;
+                    } else {
+                        const uint2 idq = *reinterpret_cast<const uint2 *>(s_ids + row * kW8Cap + e0);
+                        idw[0] = idq.x; idw[1] = idq.y;
+                    }
+                    float4 v[kW8Slots];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
+                    for (int e = 0; e < kW8Slots; ++e) {
                         const int base = (int)((idw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
                         const int off = e0 + e < deg ? tile_lane ^ base : zero_lane;   // (base has no bits below 64; tile_lane = cg base + 16 cl)
                         v[e] = *reinterpret_cast<const float4 *>(lds8 + off);
                     }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { s4[0] += v[e].x; s4[1] += v[e].y; s4[2] += v[e].z; s4[3] += v[e].w; }
+                    for (int e = 0; e < kW8Slots; ++e) { s4[0] += v[e].x; s4[1] += v[e].y; s4[2] += v[e].z; s4[3] += v[e].w; }
                 }
             } else {   // more neighbours than a list holds: walk the mask words themselves (rare, slow, same sums in another order)
                 for (int wi = 0; wi < W; ++wi) {
