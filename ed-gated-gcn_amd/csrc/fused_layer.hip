@@ -898,10 +898,6 @@ __device__ __forceinline__ float vminf_raw(float x, float y) { float d; asm("v_m
 constexpr int kW8Threads = 512;
 constexpr int kW8Ex = 8 * 16 * 1024;          // per wavefront: 4 row blocks x (2 planes x 2 k-steps) x 1 KiB
 constexpr int kW8Cap = 16;                   // source ids per row kept in LDS (rows with more neighbours walk their mask words)
-#ifndef GGCN_LAB_W8_SLOTS
-#define GGCN_LAB_W8_SLOTS 8
-#endif
-constexpr int kW8Slots = GGCN_LAB_W8_SLOTS;   // source rows in flight per pass over a row's edge list
 constexpr int kW8Stage = 4096;                // per wavefront: 32 rows x 32 columns of output on their way to 16-byte stores
 constexpr int kW8Lds = kW8Ex + 8 * kW8Stage;  // 160 KiB
 static_assert(2 * kLdsBytes <= kW8Ex && kW8Lds <= 160 * 1024, "the stage buffers of both row groups lie under the exchange area");
@@ -1178,7 +1174,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
         uint32_t mwd[8];
 #pragma unroll
         for (int wi = 0; wi < 8; ++wi) {
-            const bool ok = row < T && wi < W;
+            const bool ok = row < T && wi < W && !((GGCN_LAB_OFF) & 32);   // (timing build: no masks, empty lists)
             const uint32_t v = a.rowmask[ok ? ((int64_t)g * T + row) * W + wi : 0];
             mwd[wi] = ok ? v : 0u;
         }
@@ -1192,6 +1188,9 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                 w &= w - 1;
             }
         }
+        // the rest of the list points at row 255: a padding row for T < 256, all zeros in every tile (its X row was staged as
+        // zeros), so the sums need no test per slot; T = 256 has no such row and masks the slots instead
+        for (; e < kW8Cap; ++e) s_ids[row * kW8Cap + e] = (unsigned short)tile_off(255, 0);
         s_deg[row] = deg;
         s_inv[row] = 1.0f / (float)(deg + 1);                               // gcn.py:35
         if (tid < 32) reinterpret_cast<float *>(lds8 + zero_off)[tid] = 0.0f;
@@ -1201,7 +1200,23 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
     for (int j = 0; j < RN; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { vmax[j][k] = -INFINITY; vmin[j][k] = INFINITY; }
+    // bias and store gate of this lane's columns for both column tiles: asked for here, used behind two barriers
     const float *dummy = a.X;
+    float b4[RN][4], sg4[RN][4];
+    bool cok[RN][4];
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int col = (nt0 + j) * NT + 4 * cl + k;
+            cok[j][k] = col < F;
+            const int cc = cok[j][k] ? col : 0;
+            b4[j][k] = bias ? (bias ? bias : dummy)[cc] : 0.0f;
+            sg4[j][k] = store_gate ? (store_gate ? store_gate : dummy)[(int64_t)g * F + cc] : 1.0f;
+        }
+    const int tile_lane = cg * (256 * 128) + 16 * cl, zero_lane = zero_off + 16 * cl;
+    const int n_steps = ((GGCN_LAB_OFF) & 16) ? 1 : 16;   // (timing build: one row step only)
+    const bool full_slot = T == 256;
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
         __syncthreads();   // the tile of column tile j - 1 (j = 0: the last stage's operand planes) has been read
@@ -1215,42 +1230,39 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
         __syncthreads();   // (also: the edge lists are complete)
         if (nt0 + j >= n_tiles_total) continue;   // wavefront-uniform: column tile past F (the barriers above are met)
         const int col0 = (nt0 + j) * NT + 4 * cl;   // this lane's four columns
-        float b4[4], sg4[4];
-        bool cok[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cok[k] = col0 + k < F;
-            const int cc = cok[k] ? col0 + k : 0;
-            b4[k] = bias ? (bias ? bias : dummy)[cc] : 0.0f;
-            sg4[k] = store_gate ? (store_gate ? store_gate : dummy)[(int64_t)g * F + cc] : 1.0f;
-        }
-        const int tile_lane = cg * (256 * 128) + 16 * cl, zero_lane = zero_off + 16 * cl;
-        for (int it = 0; it < 16; ++it) {
+        // degree, reciprocal and the first 8 list entries of a row step are read one step ahead: a step is then ONE
+        // dependent LDS round trip (the source rows) instead of two
+        int deg_n = s_deg[128 * rg + q8];
+        float inv_n = s_inv[128 * rg + q8];
+        uint4 idq_n = *reinterpret_cast<const uint4 *>(s_ids + (128 * rg + q8) * kW8Cap);
+        for (int it = 0; it < n_steps; ++it) {
             if (128 * rg + 8 * it >= T) break;   // wavefront-uniform: only padding rows from here on
             const int row = 128 * rg + 8 * it + q8;
-            const int deg = s_deg[row];
-            const float inv = s_inv[row];
+            const int deg = deg_n;
+            const float inv = inv_n;
+            const uint4 idq0 = idq_n;
+            if (it + 1 < 16) {   // (rows 248..255 of the second row group exist in LDS: the lists cover all 256 slots)
+                deg_n = s_deg[row + 8];
+                inv_n = s_inv[row + 8];
+                idq_n = *reinterpret_cast<const uint4 *>(s_ids + (row + 8) * kW8Cap);
+            }
             float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (deg <= kW8Cap) {
-                for (int e0 = 0; e0 < deg; e0 += kW8Slots) {   // (rows differ per 8-lane group: plain divergent control flow)
-                    uint32_t idw[kW8Slots / 2];
-                    if constexpr (kW8Slots == 8) {
-                        const uint4 idq = *reinterpret_cast<const uint4 *>(s_ids + row * kW8Cap + e0);
-                        idw[0] = idq.x; idw[1] = idq.y; idw[kW8Slots / 2 - 2] = idq.z; idw[kW8Slots / 2 - 1] = idq.w;
-                    } else {
-                        const uint2 idq = *reinterpret_cast<const uint2 *>(s_ids + row * kW8Cap + e0);
-                        idw[0] = idq.x; idw[1] = idq.y;
-                    }
-                    float4 v[kW8Slots];
+            auto pass = [&](const uint4 &idq, int e0) {
+                const uint32_t idw[4] = {idq.x, idq.y, idq.z, idq.w};
+                float4 v[8];
 #pragma unroll
-                    for (int e = 0; e < kW8Slots; ++e) {
-                        const int base = (int)((idw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
-                        const int off = e0 + e < deg ? tile_lane ^ base : zero_lane;   // (base has no bits below 64; tile_lane = cg base + 16 cl)
-                        v[e] = *reinterpret_cast<const float4 *>(lds8 + off);
-                    }
-#pragma unroll
-                    for (int e = 0; e < kW8Slots; ++e) { s4[0] += v[e].x; s4[1] += v[e].y; s4[2] += v[e].z; s4[3] += v[e].w; }
+                for (int e = 0; e < 8; ++e) {
+                    const int base = (int)((idw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                    int off = tile_lane ^ base;   // (base has no bits below 64; tile_lane = cg base + 16 cl)
+                    if (full_slot) off = e0 + e < deg ? off : zero_lane;   // workgroup-uniform: T = 256
+                    v[e] = *reinterpret_cast<const float4 *>(lds8 + off);
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s4[0] += v[e].x; s4[1] += v[e].y; s4[2] += v[e].z; s4[3] += v[e].w; }
+            };
+            if (deg <= kW8Cap) {
+                pass(idq0, 0);   // (a row without a neighbour adds eight zeros)
+                if (deg > 8) pass(*reinterpret_cast<const uint4 *>(s_ids + row * kW8Cap + 8), 8);   // (divergent per 8-lane group)
             } else {   // more neighbours than a list holds: walk the mask words themselves (rare, slow, same sums in another order)
                 for (int wi = 0; wi < W; ++wi) {
                     uint32_t w = a.rowmask[((int64_t)g * T + row) * W + wi];
@@ -1266,19 +1278,19 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                 float o4[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float v = s4[k] * inv + b4[k];                    // gcn.py:41,43
-                    o4[k] = v * sg4[k];
+                    const float v = s4[k] * inv + b4[j][k];                 // gcn.py:41,43
+                    o4[k] = v * sg4[j][k];
                     vmax[j][k] = vmaxf_raw(vmax[j][k], v);
                     vmin[j][k] = vminf_raw(vmin[j][k], v);
                 }
-                if (out) {
+                if (out && !((GGCN_LAB_OFF) & 8)) {   // (timing build: no stores)
                     float *dst = out + ((int64_t)g * T + row) * ldo + col0;
                     if constexpr (VST) {
-                        if (cok[0]) store_out4(dst, make_float4(o4[0], o4[1], o4[2], o4[3]));
+                        if (cok[j][0]) store_out4(dst, make_float4(o4[0], o4[1], o4[2], o4[3]));
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (cok[k]) dst[k] = o4[k];
+                            if (cok[j][k]) dst[k] = o4[k];
                     }
                 }
             }
@@ -1286,7 +1298,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
     }
     // pools of the graph: max over ALL its rows (bert_amir5.py:635-640): across the 8 row classes of the wavefront (lanes 8
     // apart), then the two row groups meet in LDS
-    if (pool_a || pool_b || lp.ov_partial) {
+    if ((pool_a || pool_b || lp.ov_partial) && !((GGCN_LAB_OFF) & 64)) {   // (timing build: no pools)
 #pragma unroll
         for (int j = 0; j < RN; ++j)
 #pragma unroll
