@@ -707,9 +707,10 @@ def main():
                                                  forward_hbm_frac=(total_fwd_bytes / (alt[dflt]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                                                                    if dflt in alt else None),
                                                  headline_precision_is_opt_in=(args.precision != dflt),
-                                                 note="GraphConvolution's default keeps the whole fp32 exponent range; the headline's "
-                                                      "%s needs finite |x|, |w| < 65504 and is chosen per layer (opt.ggcn_precision / "
-                                                      "GGCN_PRECISION / module.precision)" % args.precision)
+                                                 note="GraphConvolution's default arithmetic is %s: finite |x|, |w| < 65504, watched by a "
+                                                      "sticky device flag in the kernels and reported lazily (range_guard); bf16x3 keeps "
+                                                      "the whole fp32 exponent range (opt.ggcn_precision / GGCN_PRECISION / "
+                                                      "module.precision); this run's headline precision: %s" % (dflt, args.precision))
             result["max_abs_err"] = {"precision": args.precision, "value": alt[args.precision]["max_abs_err_vs_float64"],
                                      "against": "float64 evaluation of the reference formulas on the first %d graphs of the "
                                                 "timed inputs (x1, y1, x, out); parity gate %s" %

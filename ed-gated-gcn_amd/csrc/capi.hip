@@ -248,6 +248,13 @@ int ggcn_absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float 
     return absmax(X, is_half, ld, M, K, out, as_stream(stream));
 }
 
+int ggcn_range_flag(uint32_t *flag, int clear, ggcn_stream_t stream)
+{
+    if (!flag) return fail(GGCN_EINVAL, "ggcn_range_flag: null flag pointer");
+    const int rc = range_flag_linear(flag, clear, as_stream(stream));
+    return rc ? rc : range_flag_fused(flag, clear, as_stream(stream));
+}
+
 int ggcn_transpose(const float *W, int rows, int cols, int64_t ldw, float *Wt, ggcn_stream_t stream)
 {
     return transpose_f32(W, rows, cols, ldw, Wt, as_stream(stream));

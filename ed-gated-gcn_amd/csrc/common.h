@@ -98,6 +98,8 @@ int dweight(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N,
             int64_t lddw, void *workspace, hipStream_t st);
 
 int absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float *out, hipStream_t st);
+int range_flag_linear(unsigned int *dst, int clear, hipStream_t st);   // linear_split.hip
+int range_flag_fused(unsigned int *dst, int clear, hipStream_t st);    // fused_layer.hip
 
 int transpose_f32(const float *W, int rows, int cols, int64_t ldw, float *Wt, hipStream_t st);
 int gate_mlp(const float *aspect, int64_t lda, int B, int H, const float *w1t_a, const float *b1_a, const float *w2t_a,

@@ -59,6 +59,18 @@ constexpr int SCALE_XL = 127 - XL_SHIFT, SCALE_XH = 127;
 //   4 x v_fma_mix_f32  x - float(xh)      the residual, exact (fp16 factor read straight from the pair)
 //   2 x v_cvt_scalef32_pk_fp8_f32         fp8(xl / 2^-11): the scale operand DIVIDES (cvt_probe.py)
 //   2 x v_cvt_pk_fp8_f32 of x itself      fp8(x) stands in for fp8(xh): it only feeds the correction
+// Sticky range flag: f16mx8 needs |x| < 65504 on its fp32 inputs (larger values saturate in the fp16 plane: MODE.FP16_OVFL).
+// Every main loop keeps the running maximum of |x| it splits (one v_max3 per two values) and ORs 1 into this word when it
+// reaches fp16's largest finite value -- one atomic, only when hit.  One copy per translation unit that includes this file
+// (no relocatable device code); ggcn_range_flag (capi.hip) reads / clears all of them.
+static __device__ unsigned int g_range_flag;
+__device__ __forceinline__ float amax3(float x0, float x1, float m)
+{
+    float d;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(d) : "v"(x0), "v"(x1), "v"(m));
+    return d;
+}
+
 struct Split4 {
     uint32_t h01, h23;  // fp16 pairs
     int l8, h8;         // 4 x fp8 of xl * 2^11, 4 x fp8 of x
@@ -127,6 +139,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     const int s_k = (tid % G::TPR) * EPT;
 
     set_cvt_saturate(true);
+    float amax = 0.0f;   // running max |x| of what this lane splits (range flag below)
 
     float ra[NP][EPT];
     auto load_a_pass = [&](int i, int k0) {
@@ -158,6 +171,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
                 }
             }
             sp[q] = split4(x[0], x[1], x[2], x[3]);
+            amax = amax3(x[2], x[3], amax3(x[0], x[1], amax));
         }
     };
     auto write_pass = [&](int buf, int i) {
@@ -366,6 +380,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     }
     if (st < stages) stage(st, std::integral_constant<int, 0>{});
     set_cvt_saturate(false);
+    if (amax >= 65504.0f) atomicOr(&g_range_flag, 1u);   // (inf included; a NaN input shows in the output instead)
 }
 #undef GGCN_SB
 #undef GGCN_ON

@@ -1623,4 +1623,17 @@ int overlap_reduce(const float *partials, int B, int F, float *xy, hipStream_t s
     return check_launch("ggcn_overlap_reduce");
 }
 
+// this translation unit's copy of the sticky f16mx8 range flag (f16mx8_core.h): OR it into *dst (device memory), clear on request
+__global__ void range_flag_fused_kernel(unsigned int *dst, int clear)
+{
+    const unsigned int v = mx8::g_range_flag;
+    if (v) atomicOr(dst, v);
+    if (clear) mx8::g_range_flag = 0u;
+}
+int range_flag_fused(unsigned int *dst, int clear, hipStream_t st)
+{
+    hipLaunchKernelGGL(range_flag_fused_kernel, dim3(1), dim3(1), 0, st, dst, clear);
+    return check_launch("ggcn_range_flag");
+}
+
 }  // namespace ggcn

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(64) void weight_pack_mx8_kernel(const float *__rest
         wl[jj] = w - wh[jj];
         m0 = fmaxf(m0, fabsf(wh[jj]));
         m1 = fmaxf(m1, fabsf(wl[jj]));
+        if (fabsf(w) >= 65504.0f) atomicOr(&mx8::g_range_flag, 1u);   // a weight beyond fp16: the sticky range flag (f16mx8_core.h)
     }
     m0 = fmaxf(m0, __shfl_xor(m0, 32));
     m1 = fmaxf(m1, __shfl_xor(m1, 32));
@@ -445,6 +446,19 @@ int linear_packed_h(const void *X, int64_t ldx, const void *wpack, void *Y, int6
     if (precision == GGCN_PREC_F16) return launch_linear_f16(x, ldx, wpack, y, ldy, M, K, F, st);
     if (precision == GGCN_PREC_F16MX8) return launch_linear<1, __half>(x, ldx, wpack, y, ldy, M, K, F, st);
     return launch_linear<0, __half>(x, ldx, wpack, y, ldy, M, K, F, st);
+}
+
+// this translation unit's copy of the sticky f16mx8 range flag (f16mx8_core.h): OR it into *dst (device memory), clear on request
+__global__ void range_flag_linear_kernel(unsigned int *dst, int clear)
+{
+    const unsigned int v = mx8::g_range_flag;
+    if (v) atomicOr(dst, v);
+    if (clear) mx8::g_range_flag = 0u;
+}
+int range_flag_linear(unsigned int *dst, int clear, hipStream_t st)
+{
+    hipLaunchKernelGGL(range_flag_linear_kernel, dim3(1), dim3(1), 0, st, dst, clear);
+    return check_launch("ggcn_range_flag");
 }
 
 }  // namespace ggcn

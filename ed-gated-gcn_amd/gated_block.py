@@ -17,7 +17,7 @@ also applies the gate and the max over tokens.
 """
 import torch
 
-from . import _capi
+from . import _capi, range_guard
 from .csr import BatchedCSR, tensor_version
 
 
@@ -94,6 +94,7 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
     if not training and one_launch and takes_block_path(x, csr, gc1, gc2):
         # ---- ONE launch for :626-640 (+ one 1-block launch that finishes :638) ----
         gc1._check(x)
+        range_guard.before(x.device)   # the lazy f16mx8 range report (a violation of an EARLIER launch raises here)
         lib = _capi.load_library()
         B, T, K = x.shape
         F = gc2.out_features
@@ -124,6 +125,8 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
                                              _capi.ptr(xo), F, _capi.ptr(x1), _capi.ptr(y1), _capi.ptr(out),
                                              _capi.ptr(part), _capi.PREC[kprec], st), "ggcn_block_fused")
             _capi.check(lib.ggcn_overlap_reduce(_capi.ptr(part), B, F, _capi.ptr(xy), st), "ggcn_overlap_reduce")
+        if kprec in ("f16mx8", "f16mx6"):
+            range_guard.after(x.device)
         return {"gcn1": None if gcn1 is None else gcn1.view(B, T, F), "x1": x1, "y1": y1, "xy": xy,
                 "x": xo.view(B, T, F), "out": out}
     if (not training and gc1.takes_fused_path(x, csr) and gc2.takes_fused_path(x, csr)

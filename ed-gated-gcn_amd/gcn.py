@@ -16,7 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _capi
+from . import _capi, range_guard
 from .csr import BatchedCSR, cached_from_dense, tensor_version
 
 
@@ -148,10 +148,11 @@ class GraphConvolution(nn.Module):
             self.register_parameter("bias", None)
         # arithmetic of the dense linear: "bf16x3" (3 bf16 MFMAs per product, ~1e-5 abs), "f16mx8" (fp16 MFMA
         # + one block-scaled fp8 correction MFMA, needs |x|,|w| < 65504) or "fp32" (exact fp32 MFMA).
-        # Default "bf16x3": it keeps the whole fp32 exponent range, so the one-line import switch never narrows
-        # what the reference's fp32 matmul accepts.  "f16mx8" (26 % faster) is opt-in: opt.ggcn_precision /
-        # GGCN_PRECISION, for activations of ordinary magnitude (validate_range() checks a batch).
-        self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "bf16x3")
+        # Default "f16mx8" (26 % faster than "bf16x3", the arithmetic bench.py's headline is measured in): its fp16 range
+        # is watched by the kernels themselves -- a sticky device flag set by any value >= 65504, reported lazily without
+        # a device synchronisation (range_guard; check_range() asks now) -- where the reference's fp32 matmul has no limit;
+        # "bf16x3" keeps the whole fp32 exponent range (opt.ggcn_precision / GGCN_PRECISION).
+        self.precision = getattr(opt, "ggcn_precision", None) or os.environ.get("GGCN_PRECISION", "f16mx8")
         # one-launch layer (fused_layer.hip) when the batch allows it: T <= fused_max_t, binary adjacency, split
         # precision.  128 by default; graphs of 193..256 nodes (ACE cased's ORI_ML = 231) take the eight-wavefront
         # form on their own (takes_fused_path); set 256 to send graphs of 129..192 nodes there as well.
@@ -326,6 +327,25 @@ class GraphConvolution(nn.Module):
     def forward_gated(self, text, adj, store_gate=None, pool_gate_a=None, pool_gate_b=None,
                       want_out=True, want_pool_a=False, want_pool_b=False, _internal=False,
                       overlap_partial=None, overlap_reduce=None, dropout=None):
+        """``_forward_gated`` between the two halves of the lazy f16mx8 range report (``range_guard``: no device
+        synchronisation; a violation of an EARLIER launch raises here)."""
+        guarded = (not _internal and self.precision in ("f16mx8", "f16mx6") and isinstance(text, torch.Tensor) and text.is_cuda)
+        if guarded:
+            range_guard.before(text.device)
+        r = self._forward_gated(text, adj, store_gate, pool_gate_a, pool_gate_b, want_out, want_pool_a, want_pool_b, _internal,
+                                overlap_partial, overlap_reduce, dropout)
+        if guarded:
+            range_guard.after(text.device)
+        return r
+
+    def check_range(self):
+        """Synchronous verdict of the sticky f16mx8 range flag for this layer's device (one read-back): raises if an
+        f16mx8 launch since the last report met |v| >= 65504 or an infinity."""
+        range_guard.check(self.weight.device)
+
+    def _forward_gated(self, text, adj, store_gate=None, pool_gate_a=None, pool_gate_b=None,
+                       want_out=True, want_pool_a=False, want_pool_b=False, _internal=False,
+                       overlap_partial=None, overlap_reduce=None, dropout=None):
         """Layer + gate + max-pool in one aggregation pass.
 
         Returns ``(out [B,T,F] or None, pool_a [B,F] or None, pool_b [B,F] or None)`` with

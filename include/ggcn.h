@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 7
+#define GGCN_ABI_VERSION 8
 #define GGCN_MASK_MAX_T 256   /* largest graph the row-mask (one-launch) path takes */
 
 typedef void *ggcn_stream_t;
@@ -352,6 +352,15 @@ int ggcn_scores_head(const float *X, int64_t ldx, const float *aspect, int64_t l
  * elements), out[1] = 1.0f when some entry is NaN or infinite.  f16mx8 needs |x|, |w| < 65504 and keeps
  * its full accuracy for |x| <= 448; the caller reads the two floats back when it wants the verdict. */
 int ggcn_absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float *out, ggcn_stream_t stream);
+
+/* ---- sticky range flag of GGCN_PREC_F16MX8 (what makes it safe as a default) ----------------------
+ * Every f16mx8 main loop (ggcn_linear, ggcn_layer_fused, ggcn_block_fused) keeps the running maximum of the |x| it
+ * splits and sets a sticky library flag (per device) once a value reaches fp16's largest finite value 65504 (inf
+ * included; a NaN input shows as NaN in the output instead); ggcn_weight_pack sets it for such a weight.  This call ORs
+ * the flag into *flag (device memory, 4 bytes, zeroed by the caller) in stream order and, with clear != 0, resets it:
+ * the caller copies the word to the host whenever it likes -- models/gcn.py:34 in fp32 has no such limit, so a set flag
+ * means "re-run with GGCN_PREC_BF16X3".  Costs one v_max3 per two values in the split (< 1 % of the block). */
+int ggcn_range_flag(uint32_t *flag, int clear, ggcn_stream_t stream);
 
 /* ---- sub-word -> word pooling (the step before the path) ---------------
  * Replaces models/bert_amir5.py:600 `x = torch.bmm(transform, x)`:

@@ -1138,7 +1138,7 @@ def test_dropin_forward_is_sync_free_and_shares_the_conversion(pkg, dev):
     adj = big[:, :T, :T]                                  # the reference's non-contiguous slice (bert_amir5.py:589)
     x = torch.randn(B, T, H, device=dev)
     w, b = synth.layer_params(H, H, seed=1)
-    assert pkg.GraphConvolution(H, H, None).precision == "bf16x3"        # the drop-in default keeps the fp32 range
+    assert pkg.GraphConvolution(H, H, None).precision == "f16mx8"        # the drop-in default = the benched arithmetic (range-flagged)
     promised = types.SimpleNamespace(ggcn_binary_adj=True)
     gc1, gc2 = pkg.GraphConvolution(H, H, promised).to(dev), pkg.GraphConvolution(H, H, promised).to(dev)
     plain1, plain2 = pkg.GraphConvolution(H, H, None).to(dev), pkg.GraphConvolution(H, H, None).to(dev)
@@ -1166,6 +1166,61 @@ def test_dropin_forward_is_sync_free_and_shares_the_conversion(pkg, dev):
     assert torch.equal(edited, fresh)
 
 
+
+def test_default_precision_reports_values_beyond_the_fp16_range(pkg, dev):
+    """The default arithmetic (f16mx8) needs |v| < 65504 where the reference's fp32 matmul (gcn.py:34) has no limit: the
+    kernels set a sticky per-device flag (one v_max3 per two values in the split, ggcn_range_flag), `check_range()` reads
+    it now, and without being asked a later forward raises once a polled snapshot has reached the host -- no device
+    synchronisation on the forward path.  In-range data never trips it; bf16x3 takes the same data without complaint."""
+    from ed_gated_gcn_amd import range_guard, synth
+    B, T, H = 8, 20, 64
+    adj = torch.from_numpy(synth.dependency_batch(B, T, 3.0, seed=4)).to(dev).float()
+    w, b = synth.layer_params(H, H, seed=2)
+    m = pkg.GraphConvolution(H, H, None).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(torch.from_numpy(w)); m.bias.copy_(torch.from_numpy(b))
+    m.check_range()                                       # clears whatever earlier tests left
+    x = torch.randn(B, T, H, device=dev)
+    with torch.no_grad():
+        m(x, adj)
+    m.check_range()                                       # ordinary data: nothing to report
+    big = x.clone()
+    big[3, 5, 7] = 7.0e4
+    with torch.no_grad():
+        m(big, adj)
+    with pytest.raises(RuntimeError, match="f16mx8"):
+        m.check_range()
+    m.check_range()                                       # reported once, cleared
+    # the lazy form: a violation surfaces on a later forward by itself
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        with torch.no_grad():
+            with pytest.raises(RuntimeError, match="bf16x3"):
+                for it in range(4 * range_guard.POLL_EVERY + 200):
+                    m(big if it == 0 else x, adj)
+                    if it % 8 == 7:
+                        range_guard._STATE[dev.index]["event"].synchronize() if range_guard._STATE[dev.index]["pending"] else None
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    m.check_range()
+    # an infinity counts; the one-launch block reports too
+    inf = x.clone()
+    inf[0, 0, 0] = float("inf")
+    g = torch.rand(B, H, device=dev)
+    m2 = pkg.GraphConvolution(H, H, None).to(dev)
+    with torch.no_grad():
+        m2.weight.copy_(torch.from_numpy(w)); m2.bias.copy_(torch.from_numpy(b))
+        pkg.gated_gcn_block(inf, adj, g, g, m, m2)
+    with pytest.raises(RuntimeError):
+        m.check_range()
+    # bf16x3: the fp32 range, no flag
+    m.precision = m2.precision = "bf16x3"
+    with torch.no_grad():
+        out = m(big, adj)
+    m.check_range()
+    ref = ref_dense.graph_convolution(big.cpu(), adj.cpu(), torch.from_numpy(w), torch.from_numpy(b))
+    assert float((out.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
 def test_forward_under_inference_mode(pkg, dev):
     """torch.inference_mode() tensors track no version counter: the adjacency cache and the weight-image keys must not
     read `_version` from them (a batch moved to the device inside the context is such a tensor)."""
@@ -1188,7 +1243,8 @@ def test_forward_under_inference_mode(pkg, dev):
 
 
 def test_f16mx8_range_validation_is_loud(pkg, dev):
-    """f16mx8 is opt-in and saturates beyond the fp16 range; validate_range() is the explicit check."""
+    """f16mx8 saturates beyond the fp16 range; validate_range() is the explicit up-front check of a batch and of the weights (the
+    kernels' own sticky flag: test_default_precision_reports_values_beyond_the_fp16_range)."""
     import types
     H = 64
     m = pkg.GraphConvolution(H, H, types.SimpleNamespace(ggcn_precision="f16mx8")).to(dev)
