@@ -98,6 +98,7 @@ __device__ __forceinline__ void mainloop(const float *__restrict__ xtile, uint32
     };
 
     // ---- the split: lane = (row 32 wave + lane / 2, half hb = lane & 1) ----
+    unsigned amax_bits = 0u;
     const int urow = 32 * wave + (lane >> 1), hb = lane & 1;
     const int s_raw = raw_off(urow, 4 * hb);              // chunk 4 hb + c = this address ^ (c << 4)
     const int s_h = p6_off(urow, 2 * hb);               // H plane chunks 2 hb, 2 hb + 1 (^ 16)
@@ -133,6 +134,7 @@ __device__ __forceinline__ void mainloop(const float *__restrict__ xtile, uint32
         asm("v_max_f32 %0, %1, |%2|" : "=v"(m) : "v"(m), "v"(t.x[15]));
         const float mo = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
         const unsigned mb = __float_as_uint(m) > __float_as_uint(mo) ? __float_as_uint(m) : __float_as_uint(mo);   // both >= 0: integer order
+        amax_bits = amax_bits > mb ? amax_bits : mb;   // the sticky range flag of f16mx8_core.h: largest |x| this lane has split
         int eb = (int)(mb >> 23);
         t.eb = eb < 15 ? 15 : (eb > 254 ? 254 : eb);   // kept >= 15: eb - 14 is an E8M0 byte; inf / NaN: the fp16 product decides
         t.sx = __uint_as_float((unsigned)(t.eb - 2) << 23);   // 2^(E-2): the convert DIVIDES by it
@@ -326,6 +328,7 @@ __device__ __forceinline__ void mainloop(const float *__restrict__ xtile, uint32
         stage(st + 1, std::integral_constant<int, 1>{});
     }
     if (st < stages) stage(st, std::integral_constant<int, 0>{});
+    if (amax_bits >= 0x477FE000u) atomicOr(&mx8::g_range_flag, 1u);   // |x| >= 65504 (inf and NaN patterns included)
 }
 #undef GGCN_SB6
 #undef GGCN_PIN4

@@ -358,7 +358,7 @@ int ggcn_absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float 
  * splits and sets a sticky library flag (per device) once a value reaches fp16's largest finite value 65504 (inf
  * included; a NaN input shows as NaN in the output instead); ggcn_weight_pack sets it for such a weight.  This call ORs
  * the flag into *flag (device memory, 4 bytes, zeroed by the caller) in stream order and, with clear != 0, resets it:
- * the caller copies the word to the host whenever it likes -- models/gcn.py:34 in fp32 has no such limit, so a set flag
+ * the caller copies the word to the host whenever it likes (the f16mx6 main loop sets the same flag) -- models/gcn.py:34 in fp32 has no such limit, so a set flag
  * means "re-run with GGCN_PREC_BF16X3".  Costs one v_max3 per two values in the split (< 1 % of the block). */
 int ggcn_range_flag(uint32_t *flag, int clear, ggcn_stream_t stream);
 

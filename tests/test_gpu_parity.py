@@ -1213,6 +1213,16 @@ def test_default_precision_reports_values_beyond_the_fp16_range(pkg, dev):
         pkg.gated_gcn_block(inf, adj, g, g, m, m2)
     with pytest.raises(RuntimeError):
         m.check_range()
+    # f16mx6 (same fp16 main product) reports too
+    m.precision = m2.precision = "f16mx6"
+    xb = torch.randn(8, 32, H, device=dev)
+    xb[2, 3, 4] = -9.0e4
+    adj32 = torch.from_numpy(synth.dependency_batch(8, 32, 3.0, seed=5)).to(dev).float()
+    with torch.no_grad():
+        assert m.kernel_precision(xb.reshape(-1, H), pkg.BatchedCSR.from_dense(adj32)) == "f16mx6"
+        m(xb, adj32)
+    with pytest.raises(RuntimeError):
+        m.check_range()
     # bf16x3: the fp32 range, no flag
     m.precision = m2.precision = "bf16x3"
     with torch.no_grad():
