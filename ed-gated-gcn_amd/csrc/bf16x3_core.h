@@ -123,10 +123,11 @@ __device__ __forceinline__ void load16(const AT *p, float (&v)[Geom<AT>::EPT])
 // value is exactly hi + lo, so the same three products apply).  AVEC: 16-B loads allowed
 // (K % EPT == 0, aligned).  KFULL: K % 32 == 0.  ZROWS: some rows are padding (graph slots with
 // T < 32 / past the batch).
-template <typename AT, bool AVEC, bool KFULL, bool ZROWS>
+// RBLK: only the first `nblk` of this wavefront's four 32-row blocks hold nodes (f16mx8_core.h): the others' MFMAs are skipped.
+template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int k_steps,
-                                         int wm, int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN])
+                                         int wm, int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN], int nblk = 4)
 {
     using G = Geom<AT>;
     constexpr int EPT = G::EPT, NP = G::NP;
@@ -202,6 +203,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     const int f_half = lane >> 5;
     // one 32-row block of one k-step: 2 LDS fragment reads + 6 MFMAs (3 products x 2 column tiles)
     auto mma_block = [&](int buf, int s, int i, const bf16x8 (&b)[RN][2]) {
+        if (RBLK && i >= nblk) return;   // wavefront-uniform: a block of padding rows
         // LLVM's MFMA/DS interleave strategy for this scheduling region: measured -4 % on the fused
         // layer (448 vs 467 us, same process, three orderings)
         __builtin_amdgcn_iglp_opt(0);

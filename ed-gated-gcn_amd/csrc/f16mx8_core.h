@@ -123,10 +123,12 @@ __device__ __forceinline__ int q_lds_off(int row, int chunk)
 // timing-only elimination ladder (lab_hooks.h: GGCN_LAB_OFF, 0 in the product build)
 #define GGCN_ON(bit) constexpr (!((GGCN_LAB_OFF) & (bit)))
 
-template <typename AT, bool AVEC, bool KFULL, bool ZROWS>
+// RBLK: only the first `nblk` of this wavefront's four 32-row blocks hold nodes (wavefront-uniform run-time count: the second
+// row group of a 256-row graph slot, fused_layer.hip wide8) -- the MFMAs of the others are skipped, their rows stay zero.
+template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int stages_packed, int wm,
-                                         int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN], int rot = 0)
+                                         int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN], int rot = 0, int nblk = 4)
 {
     // rot: the K loop starts at stage `rot` and wraps around (same sum, another order).  The column
     // tiles of one row block run side by side on one XCD and read the same rows of X: started one
@@ -326,21 +328,21 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
                 else aq[0] = lab_q;
             }
             GGCN_SB();
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[0], acc[i][0], 0, 0, 0);
+            if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[0], acc[i][0], 0, 0, 0);
             GGCN_SB();
             if GGCN_ON(2) { if (i < NP) split_pass(i, k_next1); }
             GGCN_SB();
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[1], acc[i][1], 0, 0, 0);
+            if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[1], acc[i][1], 0, 0, 0);
             GGCN_SB();
             if GGCN_ON(4) { if (i < NP) write_pass(buf ^ 1, i); }
             else { _Pragma("unroll") for (int q = 0; q < NQ; ++q) asm volatile("" :: "v"(sp[q].h01), "v"(sp[q].h23), "v"(sp[q].l8), "v"(sp[q].h8)); }
             GGCN_SB();
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[0], acc[i][0], 0, 0, 0);
+            if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[0], acc[i][0], 0, 0, 0);
             GGCN_SB();
             if GGCN_ON(1) { if (i < NP) load_a_pass(i, ka); }
             else { if (i < NP) { _Pragma("unroll") for (int c = 0; c < EPT; ++c) asm volatile("" : "+v"(ra[i][c])); } }
             GGCN_SB();
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[1], acc[i][1], 0, 0, 0);
+            if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[1], acc[i][1], 0, 0, 0);
             GGCN_SB();
         }
         // the MX operand of W = {fp8(wh) made here from the fp16 fragments, fp8(wl) as loaded}; b0/b1 are
@@ -363,12 +365,12 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             if GGCN_ON(8) { if (i < 3) read_q(buf, i + 1, aq[(i + 1) & 1]); }
             else { if (i < 3) aq[(i + 1) & 1] = lab_q; }
             GGCN_SB();
-            acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[0], acc[i][0], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[0]);
+            if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[0], acc[i][0], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[0]);
             GGCN_SB();
             if constexpr (GGCN_LAB_WH8) { if (i == 0) make_bm(1); }
             if GGCN_ON(16) { if (i == 0) load_bf(kstage(st + 1), b0, b1); }  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
             GGCN_SB();
-            acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[1], acc[i][1], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[1]);
+            if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[1], acc[i][1], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[1]);
             GGCN_SB();
         }
         if GGCN_ON(64) __syncthreads();

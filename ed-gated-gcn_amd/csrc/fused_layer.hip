@@ -948,10 +948,14 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
             arow[i] = a.X + ((int64_t)g * T + (avalid[i] ? r : 0)) * a.ldx;
         }
         char *stage = lds8 + rg * kLdsBytes;
+        // 32-row blocks of this row group that hold nodes: T = 160 leaves the second group one block of four -- its other MFMAs
+        // are skipped, and the SIMD it shares with a first-group wavefront gets through a stage that much sooner
+        const int rows_here = T - 128 * rg;
+        const int nblk = rows_here >= 128 ? 4 : rows_here <= 0 ? 0 : (rows_here + 31) >> 5;
         if constexpr (SCH == 0)
-            bx3::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps, 0, nt0, n_tiles_total, stage, acc);
+            bx3::mainloop<float, AVEC, KFULL, true, true>(arow, avalid, lp.wpack, K, a.k_steps, 0, nt0, n_tiles_total, stage, acc, nblk);
         else
-            mx8::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc);
+            mx8::mainloop<float, AVEC, KFULL, true, true>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc, 0, nblk);
     }
     if constexpr (GGCN_LAB_WIDE8_DENSE) {
     // every accumulator tile -> its two bf16 planes (B-operand fragments of the aggregation MFMAs), in place

@@ -294,6 +294,8 @@ class GraphConvolution(nn.Module):
                                             or any(g is not None and g.requires_grad for g in gates))
 
     WIDE_AUTO_MIN_T = 193     # graphs of 193..256 nodes fill >= 75 % of the 256-row slot of the eight-wavefront kernel
+    WIDE_AUTO_MIN_T_FULL = 161   # 161..192 nodes: only batches that fill whole rounds of workgroups (one per CU)
+    WIDE_AUTO_FILL = 0.9
 
     def takes_fused_path(self, text, csr):
         """True when ``forward_gated`` will run as ONE launch (``ggcn_layer_fused``): graphs of <= ``fused_max_t``
@@ -301,14 +303,25 @@ class GraphConvolution(nn.Module):
         ``fused_max_t`` (128 by default), graphs of 193..256 nodes (ACE cased: ``ORI_ML = 231``, ``constant.py:267``) take
         the eight-wavefront form (``layer_fused_wide8_kernel``: one workgroup per graph x 256 columns) on their own: it
         wins over linear + aggregate by 20 % on large batches (512 x 231 x 768: 399 vs 498 us) and ties on small or ragged
-        ones (128 x 231 x 768: 132 vs 132 us); graphs of 129..192 nodes leave too much of the 256-row slot empty
-        (512 x 160 x 768: 390 vs 356 us) and keep the two launches (``tools/wide_timing.py``)."""
+        ones (128 x 231 x 768: 132 vs 132 us).  Graphs of 161..192 nodes (the second row group skips the MFMAs of its
+        empty 32-row blocks) win when the workgroups fill whole rounds (512 x 176 x 768: 362 vs 391 us; 128 x 176 x 768,
+        1.5 rounds: 120 vs 102) and take it only then; shorter graphs leave too much of the 256-row slot empty
+        (512 x 129 x 768: 337 vs 294 us) and keep the two launches (``tools/wide_timing.py``)."""
         if not (self.fused and self.precision in _capi.PACKED and csr.rowmask is not None and csr.is_binary
                 and text.dtype == torch.float32):
             return False
         if csr.T <= self.fused_max_t:
             return True
-        return self.fused_max_t >= 128 and self.WIDE_AUTO_MIN_T <= csr.T <= 256
+        if self.fused_max_t < 128 or csr.T > 256:
+            return False
+        if csr.T >= self.WIDE_AUTO_MIN_T:
+            return True
+        if csr.T < self.WIDE_AUTO_MIN_T_FULL or not text.is_cuda:
+            return False
+        wgs = text.shape[0] * ((self.out_features + 255) // 256)
+        cus = torch.cuda.get_device_properties(text.device).multi_processor_count
+        rounds = -(-wgs // cus)
+        return rounds >= 2 and wgs >= self.WIDE_AUTO_FILL * rounds * cus
 
     LONG_MAX_T = 512   # include/ggcn.h GGCN_LONG_MAX_T
 

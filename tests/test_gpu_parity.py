@@ -1646,7 +1646,8 @@ def test_wide_graph_layer_one_launch_vs_oracle(pkg, dev, precision, B, T, K, F, 
 
 def test_ace_length_graphs_take_the_eight_wavefront_layer(pkg, dev):
     """Graphs of 193..256 nodes (ACE cased, ORI_ML = 231: constant.py:267) go through the one-launch layer on their own --
-    no fused_max_t set; graphs that would leave the 256-row slot mostly empty (129..192 nodes) keep linear + aggregate.
+    no fused_max_t set -- and so do graphs of 161..192 nodes in batches that fill whole rounds of workgroups; graphs that would
+    leave the 256-row slot mostly empty keep linear + aggregate.
     Both paths give the oracle's numbers; a row with more neighbours than an edge list holds (16) walks its mask words."""
     from ed_gated_gcn_amd import synth
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -1662,11 +1663,12 @@ def test_ace_length_graphs_take_the_eight_wavefront_layer(pkg, dev):
         rp, ci, _ = synth.csr_from_dense_host(adj)
         return adj, pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
     took = {}
-    for B, T in ((2 * cus, 231), (8, 231), (8, 193), (8, 192), (8, 160), (8, 129), (8, 100)):
+    for B, T in ((2 * cus, 231), (8, 231), (8, 193), (8, 192), (2 * cus, 176), (2 * cus - cus // 2, 176), (2 * cus, 160), (8, 129), (8, 100)):
         adj, csr = csr_of(B, T)
         took[(B, T)] = m.takes_fused_path(torch.empty(B, T, H, device=dev), csr)
     assert took[(2 * cus, 231)] and took[(8, 231)] and took[(8, 193)] and took[(8, 100)]
-    assert not took[(8, 192)] and not took[(8, 160)] and not took[(8, 129)]
+    assert took[(2 * cus, 176)]                      # 161..192 nodes: whole rounds of workgroups only
+    assert not took[(8, 192)] and not took[(2 * cus - cus // 2, 176)] and not took[(2 * cus, 160)] and not took[(8, 129)]
     # dense rows (> 16 neighbours: the mask-word walk) in a small batch
     adj, csr = csr_of(6, 231, degree=24.0)
     rng = np.random.default_rng(7)
