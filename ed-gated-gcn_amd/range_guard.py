@@ -69,6 +69,10 @@ def check(dev):
     """Synchronous verdict: raises RuntimeError if any f16mx8 launch on `dev` since the last report met a value outside
     fp16's range; one device read-back."""
     dev = torch.device(dev)
+    if dev.type != "cuda":
+        raise RuntimeError("range_guard.check needs a GPU device (got %s): the flag lives in libggcn_hip.so's device memory" % (dev,))
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     st = _state(dev)
     _snapshot(st, dev)
     st["pending"] = False
