@@ -183,3 +183,15 @@ def test_product_package_never_touches_the_oracle():
     code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)          # prototypes without the comments
     assert "torch" not in code.lower() and "tensor" not in code.lower()
     assert 'extern "C"' in code
+
+
+def test_default_precision_and_range_check_need_a_gpu():
+    """The module's default arithmetic is the benched one (f16mx8, range-flagged by the kernels); asking for the flag of a
+    module that is not on a GPU fails loudly instead of answering from the host."""
+    import pytest
+    import ed_gated_gcn_amd as pkg
+    m = pkg.GraphConvolution(8, 8, None)
+    assert m.precision == "f16mx8"
+    with pytest.raises(RuntimeError, match="GPU"):
+        m.check_range()
+
