@@ -16,7 +16,7 @@ for it in range(cases):
     T = int(rng.choice([33, 40, 64, 65, 96, 100, 128, 129, 150, 192, 193, 200, 231, 255, 256]))
     B = int(rng.integers(1, 12))
     K = int(rng.choice([32, 64, 96, 100, 128, 250, 256]))
-    F = int(rng.choice([32, 60, 64, 100, 128, 256, 260, 300, 512]))
+    F = int(rng.choice([int(v) for v in os.environ["FUZZ_F"].split(",")] if os.environ.get("FUZZ_F") else [32, 60, 64, 100, 128, 256, 260, 300, 512]))
     deg = float(rng.choice([2.0, 4.0, 9.0, 20.0]))
     prec = str(rng.choice(["f16mx8", "bf16x3"]))
     lens = np.array([T] + [int(v) for v in rng.integers(max(1, T // 3), T + 1, size=B - 1)])
