@@ -391,7 +391,7 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
 #pragma unroll
             for (int p = 1; p >= 0; --p)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) y[j] = P::mma(afv[s], hf[p][s], y[j]);
+                for (int s = 0; s < 2; ++s) { if constexpr (!((GGCN_LAB_EPI) & 2)) y[j] = P::mma(afv[s], hf[p][s], y[j]); else y[j][s] += (float)hf[p][s][0]; }
         }
         float rinv[16];
 #pragma unroll
@@ -491,7 +491,7 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
             for (int it = 0; it < 8; ++it) {
                 const int row = 4 * it + (lane >> 4);
                 const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 64 + (colq ^ (32 * ((row >> 2) & 1)))]);
-                if ((FULLT || row < T) && gcol < F) store_out4(gbase + row * ldo, v4);
+                if ((FULLT || row < T) && gcol < F && !((GGCN_LAB_EPI) & 1)) store_out4(gbase + row * ldo, v4);   // (GGCN_LAB_EPI 1: timing build without the stores)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();

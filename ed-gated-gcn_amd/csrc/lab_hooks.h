@@ -22,6 +22,9 @@
 #ifndef GGCN_LAB_WIDE8_DENSE
 #define GGCN_LAB_WIDE8_DENSE 0   // 1: layer_fused_wide8_kernel aggregates with dense 32 x 32 adjacency blocks on the MFMAs (its first form)
 #endif
+#ifndef GGCN_LAB_EPI
+#define GGCN_LAB_EPI 0           // timing-only switches of the 32-node epilogue: 1 = no [N,F] stores, 2 = no aggregation MFMAs (first application)
+#endif
 #ifndef GGCN_LAB_WIDE_SB8
 #define GGCN_LAB_WIDE_SB8 0   // 1: graphs of 129..256 nodes through the older lone-wavefront form (layer_fused_wide_kernel<.., 8>)
 #endif
