@@ -36,6 +36,7 @@ PROTOTYPES = {
                                  c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "ggcn_absmax": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "ggcn_range_flag": (c_i32, [c_vp, c_i32, c_vp]),
+    "ggcn_debug_poison_lds": (c_i32, [ctypes.c_uint32, c_vp]),
     "ggcn_subword_pool": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                                   c_i32, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_weight_pack_bytes": (c_sz, [c_i32, c_i32, c_i32]),

@@ -248,6 +248,8 @@ int ggcn_absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float 
     return absmax(X, is_half, ld, M, K, out, as_stream(stream));
 }
 
+int ggcn_debug_poison_lds(uint32_t pattern, ggcn_stream_t stream) { return poison_lds(pattern, as_stream(stream)); }
+
 int ggcn_range_flag(uint32_t *flag, int clear, ggcn_stream_t stream)
 {
     if (!flag) return fail(GGCN_EINVAL, "ggcn_range_flag: null flag pointer");

@@ -98,6 +98,7 @@ int dweight(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N,
             int64_t lddw, void *workspace, hipStream_t st);
 
 int absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float *out, hipStream_t st);
+int poison_lds(uint32_t pattern, hipStream_t st);                       // range_check.hip (test hook)
 int range_flag_linear(unsigned int *dst, int clear, hipStream_t st);   // linear_split.hip
 int range_flag_fused(unsigned int *dst, int clear, hipStream_t st);    // fused_layer.hip
 

@@ -36,7 +36,38 @@ __global__ __launch_bounds__(256) void absmax_kernel(const ET *__restrict__ X, i
     }
 }
 
+// Test hook (ggcn_debug_poison_lds): every CU's whole LDS (160 KiB) is filled with `pattern`, so that the NEXT kernel on
+// the stream finds known garbage where the hardware would otherwise leave whatever the previous kernels stored.  A
+// workgroup takes all of a CU's LDS (one per CU at a time) and stays for `hold` ticks of the 100 MHz clock, so the first
+// 256 workgroups of the grid land on 256 different CUs.  tests/test_gpu_parity.py runs the LDS-heavy kernels behind
+// different patterns and demands bit-identical results: a read of LDS the launch itself did not write cannot hide.
+constexpr int kPoisonLds = 160 * 1024;
+__global__ __launch_bounds__(1024) void lds_poison_kernel(uint32_t pattern, int hold, unsigned int *__restrict__ sink)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t plds[];
+    for (int i = threadIdx.x; i < kPoisonLds / 4; i += 1024) plds[i] = pattern;
+    __syncthreads();
+    const uint64_t t0 = wall_clock64();
+    while ((int64_t)(wall_clock64() - t0) < hold) __builtin_amdgcn_s_sleep(16);
+    if (plds[(threadIdx.x * 37u + blockIdx.x) % (kPoisonLds / 4)] != pattern) atomicAdd(sink, 1u);   // keeps the stores alive
+}
+static __device__ unsigned int g_poison_sink;
+
 }  // namespace
+
+int poison_lds(uint32_t pattern, hipStream_t st)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return fail(GGCN_ELAUNCH, "ggcn_debug_poison_lds: cannot read the device's CU count");
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPoisonLds) != hipSuccess)
+        return fail(GGCN_ELAUNCH, "ggcn_debug_poison_lds: cannot reserve %d bytes of LDS", kPoisonLds);
+    unsigned int *sink = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void **>(&sink), HIP_SYMBOL(g_poison_sink)) != hipSuccess)
+        return fail(GGCN_ELAUNCH, "ggcn_debug_poison_lds: no sink");
+    hipLaunchKernelGGL(lds_poison_kernel, dim3((unsigned)(4 * cus)), dim3(1024), kPoisonLds, st, pattern, 500 /* 5 us */, sink);
+    return check_launch("ggcn_debug_poison_lds");
+}
 
 int absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float *out, hipStream_t st)
 {

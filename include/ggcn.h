@@ -362,6 +362,14 @@ int ggcn_absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float 
  * means "re-run with GGCN_PREC_BF16X3".  Costs one v_max3 per two values in the split (< 1 % of the block). */
 int ggcn_range_flag(uint32_t *flag, int clear, ggcn_stream_t stream);
 
+/* ---- test hook: known garbage in every CU's LDS ---------------------------------------------------
+ * Fills the whole LDS (160 KiB) of every CU with the 32-bit `pattern`, in stream order: the next kernel on the stream
+ * starts on LDS whose stale contents are known.  The hardware never clears LDS between kernels, so a kernel that reads
+ * a location it did not write itself returns whatever an EARLIER kernel left there -- a result that depends on the
+ * process's history (models/gcn.py:41 and bert_amir5.py:635-640 have no such state).  The parity tests run every
+ * LDS-resident path behind several patterns (+inf, -inf, NaN / id 0xFFFF) and demand bit-identical outputs. */
+int ggcn_debug_poison_lds(uint32_t pattern, ggcn_stream_t stream);
+
 /* ---- sub-word -> word pooling (the step before the path) ---------------
  * Replaces models/bert_amir5.py:600 `x = torch.bmm(transform, x)`:
  *   Y[b,r,:] = sum_c A[b,r,c] * X[b,c,:]

@@ -896,6 +896,128 @@ def test_fp16_long_graphs_random_shapes_match_two_launches_bitwise(pkg, dev):
                         case, rep, B, T, K, F, deg, weighted, name, float((u.float() - v.float()).abs().max()))
 
 
+POISONS = (0x7F800000, 0xFF800000, 0xFFFFFFFF, 0x7C007C00)   # +inf, -inf, NaN / id 65535, fp16 +inf pairs
+
+
+def _poison_lds(pkg, dev, pattern):
+    """Known garbage in every CU's LDS before the next launch (ggcn_debug_poison_lds, include/ggcn.h)."""
+    from ed_gated_gcn_amd import _capi
+    lib = pkg.load_library()
+    with torch.cuda.device(dev):
+        _capi.check(lib.ggcn_debug_poison_lds(pattern, _capi.stream_of(dev)), "ggcn_debug_poison_lds")
+
+
+@pytest.mark.parametrize("B,T,K,F,degree,weighted", [(9, 129, 192, 128, 4.0, False), (3, 512, 128, 256, 6.0, False),
+                                                       (2, 300, 64, 136, 5.0, True), (2, 512, 64, 72, 20.0, False),
+                                                       (3, 200, 64, 64, 4.0, True)])
+def test_long_graph_layer_is_a_function_of_what_it_was_given(pkg, dev, B, T, K, F, degree, weighted):
+    """Round 3 saw ONE run of the (9, 129, 192, 128) case return +inf in a pool of layer_fused_long_kernel and could not
+    make it happen again.  An exact +inf there is a max/min initialiser (fused_long.hip: vmax = -inf, vmin = +inf) or stale
+    memory reaching the reduction, i.e. a read of something this launch did not write: LDS left by EARLIER kernels (the
+    hardware never clears it), `colidx` / `vals` entries behind the last edge (torch.empty), the previous contents of the
+    output buffers.  This test makes every one of those sources hostile and deterministic -- every CU's LDS filled with
+    +inf / -inf / NaN / fp16-inf patterns right before the launch, the CSR tails filled with out-of-range ids and NaN,
+    the outputs pre-filled with NaN -- and demands results BIT-IDENTICAL to a launch behind zeroed LDS and clean tails,
+    with the first case being the one that failed (odd stage count: the last stage's LDS-DMA repeats land in W buffer 1,
+    under the pools' exchange area; third row pass with one live 8-lane group)."""
+    from ed_gated_gcn_amd import _capi, synth
+    lib = pkg.load_library()
+    rng = np.random.default_rng(T + K)
+    lens = np.array([T] + [int(v) for v in rng.integers(T // 3, T + 1, size=B - 1)])
+    adj = synth.dependency_batch(B, T, min(degree, T), seed=T, lengths=lens).astype(np.float32)
+    if weighted:
+        adj = adj * rng.uniform(0.25, 2.0, size=adj.shape).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((B, T, K)).astype(np.float32)).half().to(dev)
+    g1 = torch.from_numpy(rng.uniform(-1.0, 1.0, (B, F)).astype(np.float32)).to(dev)
+    g2 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32))).to(dev)
+    w, b = synth.layer_params(K, F, seed=5)
+    m = _layer(pkg, dev, w, b, "f16")
+    csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj).to(dev))
+    nnz = int(csr.rowptr[-1].item())
+    p, st = _capi.ptr, _capi.stream_of(dev)
+    pack = m._packed_weight(lib, st)
+    bias = m.bias.detach()
+
+    def launch(colidx, vals, want_out=True):
+        out = torch.full((B * T, F), float("nan"), dtype=torch.float16, device=dev) if want_out else None
+        pa = torch.full((B, F), float("nan"), device=dev)
+        pb = torch.full((B, F), float("nan"), device=dev)
+        _capi.check(lib.ggcn_layer_fused_h(p(x), K, p(pack), p(csr.rowptr), p(colidx), p(vals), p(bias), B, T, K, F, p(g2),
+                                           p(g1), p(g2), p(out), F, p(pa), p(pb), st), "ggcn_layer_fused_h")
+        return out, pa, pb
+
+    _poison_lds(pkg, dev, 0)
+    ref = launch(csr.colidx, csr.vals)
+    assert all(bool(torch.isfinite(t.float()).all()) for t in ref)
+    # hostile tails: an id that is no node of any graph, a weight that poisons any sum it enters
+    col_bad = csr.colidx.clone()
+    col_bad[nnz:] = 0x7FFFFFFF
+    val_bad = None
+    if csr.vals is not None:
+        val_bad = csr.vals.clone()
+        val_bad[nnz:] = float("nan")
+    for pattern in POISONS:
+        for want_out in (True, False):
+            _poison_lds(pkg, dev, pattern)
+            got = launch(col_bad, val_bad, want_out)
+            for name, u, v in zip(("out", "pool_a", "pool_b"), got, ref):
+                if u is not None:
+                    assert torch.equal(u, v), "LDS pattern %#x, %s: differs from the clean launch in %d places" % (
+                        pattern, name, int((u != v).sum()))
+    # against the oracle too (config 4's gate on the fp16-rounded inputs)
+    oref = ref_dense.graph_convolution(x.float().cpu(), torch.from_numpy(adj), torch.from_numpy(w), torch.from_numpy(b))
+    scale = max(1.0, float(oref.abs().max()))
+    np.testing.assert_allclose(ref[1].cpu().numpy(), (oref * g1.cpu()[:, None, :]).max(dim=1)[0].numpy(), rtol=0, atol=2e-3 * scale)
+
+
+def test_lds_resident_paths_do_not_read_stale_lds(pkg, dev):
+    """The same demand on every other kernel that keeps state in LDS: the one-launch block and layer (graphs of <= 32
+    nodes: operand blocks, gates and store staging behind the stage buffers), the 64-/128-row and the eight-wavefront
+    forms (33..256 nodes), the LDS-slab aggregation (T <= 48) and the long-graph aggregation -- each run behind four
+    hostile LDS patterns and compared bit for bit with the run behind zeroed LDS."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(77)
+
+    def case(B, T, H, precision, fused, half=False, block=False):
+        lens = rng.integers(max(1, T // 3), T + 1, size=B)
+        adj = torch.from_numpy(synth.dependency_batch(B, T, min(4.0, T), seed=T + B, lengths=lens).astype(np.float32)).to(dev)
+        x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32)).to(dev)
+        x = x.half() if half else x
+        g1 = torch.from_numpy(rng.uniform(-1.0, 1.0, (B, H)).astype(np.float32)).to(dev)
+        g2 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32))).to(dev)
+        w1, b1 = synth.layer_params(H, H, seed=1)
+        w2, b2 = synth.layer_params(H, H, seed=2)
+        l1, l2 = _layer(pkg, dev, w1, b1, precision, fused=fused), _layer(pkg, dev, w2, b2, precision, fused=fused)
+        csr = pkg.BatchedCSR.from_dense(adj)
+
+        def run():
+            with torch.no_grad():
+                if block:
+                    r = pkg.gated_gcn_block(x, csr, g1, g2, l1, l2, want_gcn1=True, one_launch=True)
+                    return [r[k] for k in ("gcn1", "x1", "y1", "x", "out")] + [r["xy"].reshape(1)]
+                return list(l1.forward_gated(x, csr, store_gate=g2, pool_gate_a=g1, pool_gate_b=g2, want_pool_a=True, want_pool_b=True))
+        run()                      # weight images, operand blocks, caches: made outside the compared launches
+        _poison_lds(pkg, dev, 0)
+        ref = run()
+        for pattern in POISONS:
+            _poison_lds(pkg, dev, pattern)
+            got = run()
+            for k, (u, v) in enumerate(zip(got, ref)):
+                assert torch.equal(u, v), "B=%d T=%d H=%d %s fused=%s block=%s, LDS pattern %#x: output %d differs" % (
+                    B, T, H, precision, fused, block, pattern, k)
+
+    case(37, 32, 256, "f16mx8", True, block=True)      # ggcn_block_fused
+    case(37, 19, 256, "bf16x3", True, block=True)
+    case(10, 32, 320, "f16mx6", True, block=True)      # layer_fused6_kernel (RAW stages reused for the operands)
+    case(21, 31, 200, "f16mx8", True)                  # ggcn_layer_fused, ragged T < 32, F % 32 != 0
+    case(9, 100, 256, "f16mx8", True)                  # 128-row slots
+    case(9, 60, 256, "bf16x3", True)                   # 64-row slots
+    case(5, 231, 512, "f16mx8", True)                  # eight wavefronts per graph (edge lists out of an fp32 tile)
+    case(5, 150, 256, "bf16x3", True)
+    case(17, 40, 256, "f16mx8", False)                 # linear + LDS-slab aggregation
+    case(3, 300, 256, "f16", False, half=True)         # long-graph aggregation (aggregate_narrow)
+
+
 def test_fp16_long_graph_entry_refuses_what_it_cannot_run(pkg, dev):
     from ed_gated_gcn_amd import _capi, synth
     lib = pkg.load_library()
