@@ -87,6 +87,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to "
                     "rehearse the N>1 code path on a one-GPU box together with --same-device")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 step loop (process group, hipGraph replay, logits head, asynchronous all-gather per "
+                         "step) at ANY world size -- with --gpus 1 this is RCCL's whole code path on a one-GPU box "
+                         "(tests/test_gpu_parity.py drives it with --backend nccl)")
     ap.add_argument("--cpu-graphs", type=int, default=None, help="sample size of the CPU baseline")
     ap.add_argument("--check-gather", action="store_true",
                     help="N > 1: after the timed region rank 0 recomputes the UNSHARDED batch on its own GPU and compares "
@@ -294,7 +298,17 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
     dev = torch.device("cuda", 0 if args.same_device else local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # the distributed branch: every N > 1 run, and N = 1 on request (--force-dist: the same loop with a process group of one)
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        if "MASTER_ADDR" not in os.environ:   # a plain `python bench.py --gpus 1 --force-dist`: rendezvous with ourselves
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(args.master_port or port), "RANK": "0",
+                               "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -356,7 +370,7 @@ def main():
     # a replicated synthetic Wd, one small GEMM per step inside the timed region.  "pooled": out [B_r, H] itself.
     N_CLASS = 34
     head = None
-    if world > 1 and args.gather == "logits":
+    if dist_on and args.gather == "logits":
         head = (torch.randn(H, N_CLASS, generator=torch.Generator().manual_seed(7)) / H ** 0.5).to(dev)
 
     def forward(xx=None, cc=None, a1=None, a2=None, path=None):
@@ -375,9 +389,9 @@ def main():
 
     # the path's only collective: all-gather of the per-shard logits [B_r, 34] (or pooled outputs [B_r, H]), launched
     # asynchronously so step i's gather (RCCL's stream, xGMI) overlaps step i+1's kernels
-    gather = shard.PooledGather(counts, N_CLASS if head is not None else H, dev) if world > 1 else None
+    gather = shard.PooledGather(counts, N_CLASS if head is not None else H, dev) if dist_on else None
     pending = []
-    capture = args.capture == "on" or (args.capture == "auto" and world > 1)
+    capture = args.capture == "on" or (args.capture == "auto" and dist_on)
     set_mode(args.precision, args.path)
     graphs = None
     capture_note = None
@@ -402,7 +416,7 @@ def main():
                 g, r = graphs[counter[0] & 1]
                 g.replay()
             counter[0] += 1
-            if world > 1:
+            if dist_on:
                 pending.append(gather.start(r["payload"] if head is not None else r["out"]))
         return r
 
@@ -410,7 +424,7 @@ def main():
         while pending:
             last_gathered[0] = gather.finish(pending.pop(0))
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -426,7 +440,7 @@ def main():
             dt = time.perf_counter() - t0
             n_pre += 50
             settled = last is not None and abs(dt - last) <= 0.01 * dt and n_pre >= 150
-            if world > 1:
+            if dist_on:
                 flag = torch.tensor([1 if settled else 0], device=dev)
                 dist.broadcast(flag, src=0)
                 settled = bool(flag.item())
@@ -449,7 +463,7 @@ def main():
         return evs
     # An event record is a barrier packet on the stream (~2-3 us of GPU time each): with a short step (a small
     # shard) only every 4th step carries the per-launch events and the step events bracket 4 steps at a time.
-    sparse = last is not None and (last / 50) < 300e-6 if args.precondition < 0 else (world > 1)
+    sparse = last is not None and (last / 50) < 300e-6 if args.precondition < 0 else dist_on
     ev_stride = 4 if sparse else 1
     k_stride = 4          # the per-launch events of the dominant kernel ride on every 4th step (two barrier packets each)
     kernel_events = {}
@@ -504,7 +518,7 @@ def main():
     if os.environ.get("GGCN_BENCH_SERIES") and rank == 0:   # development aid: where the slow steps sit
         print("step_us series:", " ".join("%.0f" % v for v in step_us), file=sys.stderr)
     kern_us = {k: [a.elapsed_time(b) * 1e3 for a, b in v] for k, v in kernel_events.items()}
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -517,7 +531,7 @@ def main():
 
     # ---- N > 1: what the collective moved, and (on request) the gathered payload against the unsharded batch ----
     rccl = gather_check = None
-    if world > 1:
+    if dist_on:
         width = N_CLASS if head is not None else H
         rccl = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
                 "gather_bytes_per_rank": int(max(counts)) * width * 4,
@@ -627,7 +641,7 @@ def main():
         ref64 = block_float64(x_cpu[:ns].float(), sub_adj, g1_cpu[:ns], g2_cpu[:ns], t_(w1), t_(b1), t_(w2), t_(b2),
                               one_layer)
         xs, g1s, g2s = x[:ns].contiguous(), g1[:ns].contiguous(), g2[:ns].contiguous()
-        precs = ["f16", "f16mx8", "bf16x3"] if half else ["f16mx8", "f16mx6", "bf16x3", "fp32"]
+        precs = ["f16", "f16mx8", "bf16x3"] if half else (["f16mx8"] + (["f16mx6"] if _capi.has_f16mx6() else []) + ["bf16x3", "fp32"])
         for prec in precs:
             set_mode(prec, args.path)
             with torch.no_grad():
@@ -707,8 +721,9 @@ def main():
                                                  forward_hbm_frac=(total_fwd_bytes / (alt[dflt]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                                                                    if dflt in alt else None),
                                                  headline_precision_is_opt_in=(args.precision != dflt),
-                                                 note="GraphConvolution's default arithmetic is %s: finite |x|, |w| < 65504, watched by a "
-                                                      "sticky device flag in the kernels and reported lazily (range_guard); bf16x3 keeps "
+                                                 note="GraphConvolution's default arithmetic is %s: inside the 1e-4 gate for |x| <= 448 and hidden "
+                                                      "values < 65504, both watched by a sticky device flag in the kernels and reported "
+                                                      "lazily (range_guard: overflow / accuracy window / hidden bound); bf16x3 keeps "
                                                       "the whole fp32 exponent range (opt.ggcn_precision / GGCN_PRECISION / "
                                                       "module.precision); this run's headline precision: %s" % (dflt, args.precision))
             result["max_abs_err"] = {"precision": args.precision, "value": alt[args.precision]["max_abs_err_vs_float64"],
@@ -725,7 +740,7 @@ def main():
             result["ace_cased"] = ace_block(pkg, synth, torch, dev, args.precision if args.precision in ("bf16x3", "f16mx8") else "f16mx8")
             result["config4"] = config4_block()
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     return result

@@ -16,6 +16,7 @@ c_i32, c_i64, c_vp, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes
 # name -> (restype, argtypes): exactly the prototypes of include/ggcn.h
 PROTOTYPES = {
     "ggcn_abi_version": (c_i32, []),
+    "ggcn_has_f16mx6": (c_i32, []),
     "ggcn_last_error": (ctypes.c_char_p, []),
     "ggcn_csr_workspace_bytes": (c_sz, [c_i64]),
     "ggcn_csr_from_dense": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp,
@@ -66,10 +67,16 @@ PROTOTYPES = {
     "ggcn_gate_overlap": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2, "f16": 3, "f16mx6": 4}
 PACKED = ("bf16x3", "f16mx8", "f16", "f16mx6")  # precisions whose linear reads a ggcn_weight_pack image ("f16": half features only)
 FLAG_WEIGHTED = 1
+RANGE_OVERFLOW, RANGE_WINDOW, RANGE_HIDDEN = 1, 2, 4   # include/ggcn.h ggcn_range_bits
+
+
+def has_f16mx6():
+    """True when libggcn_hip.so was built with the experimental fp6-correction kernel (``make F16MX6=1``)."""
+    return bool(load_library().ggcn_has_f16mx6())
 
 
 def lib_path():

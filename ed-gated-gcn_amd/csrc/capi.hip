@@ -31,6 +31,15 @@ extern "C" {
 
 int ggcn_abi_version(void) { return GGCN_ABI_VERSION; }
 
+int ggcn_has_f16mx6(void)
+{
+#ifdef GGCN_WITH_F16MX6
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 const char *ggcn_last_error(void) { return error_buffer(); }
 
 size_t ggcn_csr_workspace_bytes(int64_t n_rows) { return csr_workspace_bytes(n_rows); }
@@ -253,8 +262,15 @@ int ggcn_debug_poison_lds(uint32_t pattern, ggcn_stream_t stream) { return poiso
 int ggcn_range_flag(uint32_t *flag, int clear, ggcn_stream_t stream)
 {
     if (!flag) return fail(GGCN_EINVAL, "ggcn_range_flag: null flag pointer");
-    const int rc = range_flag_linear(flag, clear, as_stream(stream));
-    return rc ? rc : range_flag_fused(flag, clear, as_stream(stream));
+    // one copy of the flag per translation unit that holds an f16mx8 main loop
+    int rc = range_flag_linear(flag, clear, as_stream(stream));
+    rc = rc ? rc : range_flag_fused(flag, clear, as_stream(stream));
+    rc = rc ? rc : range_flag_wide(flag, clear, as_stream(stream));
+    rc = rc ? rc : range_flag_wide8(flag, clear, as_stream(stream));
+#ifdef GGCN_WITH_F16MX6
+    rc = rc ? rc : range_flag_fused6(flag, clear, as_stream(stream));
+#endif
+    return rc;
 }
 
 int ggcn_transpose(const float *W, int rows, int cols, int64_t ldw, float *Wt, ggcn_stream_t stream)

@@ -101,6 +101,9 @@ int absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float *out,
 int poison_lds(uint32_t pattern, hipStream_t st);                       // range_check.hip (test hook)
 int range_flag_linear(unsigned int *dst, int clear, hipStream_t st);   // linear_split.hip
 int range_flag_fused(unsigned int *dst, int clear, hipStream_t st);    // fused_layer.hip
+int range_flag_wide(unsigned int *dst, int clear, hipStream_t st);     // fused_wide.hip
+int range_flag_wide8(unsigned int *dst, int clear, hipStream_t st);    // fused_wide8.hip
+int range_flag_fused6(unsigned int *dst, int clear, hipStream_t st);   // fused6.hip (GGCN_WITH_F16MX6)
 
 int transpose_f32(const float *W, int rows, int cols, int64_t ldw, float *Wt, hipStream_t st);
 int gate_mlp(const float *aspect, int64_t lda, int B, int H, const float *w1t_a, const float *b1_a, const float *w2t_a,

@@ -73,7 +73,8 @@ __device__ __forceinline__ int raw_off(int row, int c) { return row * 128 + ((c 
 template <bool ZROWS>
 __device__ __forceinline__ void mainloop(const float *__restrict__ xtile, uint32_t xtile_bytes, const uint32_t (&aoff)[2],
                                          uint32_t piece_stride, bool uvalid, const char *__restrict__ wpack, int K,
-                                         int stages_packed, int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN])
+                                         int stages_packed, int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN],
+                                         float *amax_out = nullptr)
 {
     static_assert(RN == 2 && BK == 32, "written for 128 x 64 wavefront tiles and 32-deep stages");
     const int tid = threadIdx.x;
@@ -328,7 +329,10 @@ __device__ __forceinline__ void mainloop(const float *__restrict__ xtile, uint32
         stage(st + 1, std::integral_constant<int, 1>{});
     }
     if (st < stages) stage(st, std::integral_constant<int, 0>{});
-    if (amax_bits >= 0x477FE000u) atomicOr(&mx8::g_range_flag, 1u);   // |x| >= 65504 (inf and NaN patterns included)
+    // the sticky range flag (f16mx8_core.h): the block scales have no accuracy window, the fp16 main product has fp16's range
+    const float amax = amax_bits >= 0x7F800000u ? __builtin_inff() : __uint_as_float(amax_bits);
+    if (amax_out) *amax_out = amax;
+    else mx8::range_verdict(amax, 0.0f, 0.0f, false);
 }
 #undef GGCN_SB6
 #undef GGCN_PIN4

@@ -63,7 +63,40 @@ constexpr int SCALE_XL = 127 - XL_SHIFT, SCALE_XH = 127;
 // Every main loop keeps the running maximum of |x| it splits (one v_max3 per two values) and ORs 1 into this word when it
 // reaches fp16's largest finite value -- one atomic, only when hit.  One copy per translation unit that includes this file
 // (no relocatable device code); ggcn_range_flag (capi.hip) reads / clears all of them.
+// Bits of the flag (ggcn.h GGCN_RANGE_*): 1 = a value reached 65504 (fp16 saturates: results wrong); 2 = a value left the
+// window |x| <= 448 in which the fp8 correction is exact to its format (beyond it the correction saturates and the product
+// falls to plain fp16 accuracy, 2^-12 relative: outside the 1e-4 parity gate); 4 = the one-launch layer of graphs of
+// <= 32 nodes could not rule out an fp16 overflow of its `hidden` planes (max|x| * max_f sum_k |w[k,f]| (+ max|mid|) >= 65504).
 static __device__ unsigned int g_range_flag;
+constexpr float kWindow = 448.0f;       // largest e4m3 value: fp8(x) and fp8(xl * 2^11) are unsaturated up to here
+constexpr float kHalfMax = 65504.0f;
+// verdict of one lane: amax = the largest |x| it split; hb_scale / hb_add: bound of the hidden values (0: not applicable)
+__device__ __forceinline__ void range_verdict(float amax, float hb_scale = 0.0f, float hb_add = 0.0f, bool window = true)
+{
+    unsigned bits = 0u;
+    if (window && amax > kWindow) bits |= 2u;   // (f16mx6's true block scales have no such window)
+    if (amax >= kHalfMax) bits |= 1u;   // (inf included; a NaN input shows in the output instead)
+    if (amax * hb_scale + hb_add >= kHalfMax) bits |= 4u;
+    if (bits) atomicOr(&g_range_flag, bits);
+}
+// this translation unit's copy of the flag: OR it into *dst (device memory), clear on request
+#define GGCN_RANGE_FLAG_TU(fn)                                                                          \
+    namespace {                                                                                         \
+    __global__ void fn##_kernel(unsigned int *dst, int clear)                                           \
+    {                                                                                                   \
+        const unsigned int v = mx8::g_range_flag;                                                       \
+        if (v) atomicOr(dst, v);                                                                        \
+        if (clear) mx8::g_range_flag = 0u;                                                              \
+    }                                                                                                   \
+    }                                                                                                   \
+    int fn(unsigned int *dst, int clear, hipStream_t st)                                                \
+    {                                                                                                   \
+        hipLaunchKernelGGL(fn##_kernel, dim3(1), dim3(1), 0, st, dst, clear);                           \
+        return check_launch("ggcn_range_flag");                                                         \
+    }
+// The packed weight images end in a 16-byte trailer: float[0] = max_f sum_k |w[k,f]| (ggcn_weight_pack), the factor of the
+// hidden-value bound above.
+constexpr int PACK_TRAILER_BYTES = 16;
 __device__ __forceinline__ float amax3(float x0, float x1, float m)
 {
     float d;
@@ -128,7 +161,8 @@ __device__ __forceinline__ int q_lds_off(int row, int chunk)
 template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int stages_packed, int wm,
-                                         int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN], int rot = 0, int nblk = 4)
+                                         int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN], int rot = 0, int nblk = 4,
+                                         float *amax_out = nullptr)
 {
     // rot: the K loop starts at stage `rot` and wraps around (same sum, another order).  The column
     // tiles of one row block run side by side on one XCD and read the same rows of X: started one
@@ -382,7 +416,8 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     }
     if (st < stages) stage(st, std::integral_constant<int, 0>{});
     set_cvt_saturate(false);
-    if (amax >= 65504.0f) atomicOr(&g_range_flag, 1u);   // (inf included; a NaN input shows in the output instead)
+    if (amax_out) *amax_out = amax;   // the caller adds its own bound to the verdict (fused_layer.hip)
+    else range_verdict(amax);
 }
 #undef GGCN_SB
 #undef GGCN_ON

@@ -365,6 +365,34 @@ int launch_linear(const ET *X, int64_t ldx, const void *wpack, ET *Y, int64_t ld
     return check_launch("ggcn_linear(bf16x3)");
 }
 
+// trailer of the f16mx8 / f16 / f16mx6 images: max over the columns of sum_k |w[k,f]| (one thread per column, coalesced over
+// the columns of a row-major W; non-negative floats order like their bit patterns)
+template <bool TR>
+__global__ __launch_bounds__(256) void weight_colabs_kernel(const float *__restrict__ W, int64_t ldw, int K, int F,
+                                                            unsigned int *__restrict__ trailer)
+{
+    __shared__ float red[4];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.0f;
+    if (n < F)
+        for (int k = 0; k < K; ++k) s += fabsf(TR ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n]);
+    if (!(s <= 3.0e38f)) s = __builtin_inff();   // NaN / overflow: no bound
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s = fmaxf(s, __shfl_xor(s, d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(trailer, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
+int pack_trailer(const float *W, int64_t ldw, int K, int F, bool transposed, char *trailer, hipStream_t st)
+{
+    if (hipMemsetAsync(trailer, 0, mx8::PACK_TRAILER_BYTES, st) != hipSuccess) return fail(GGCN_ELAUNCH, "ggcn_weight_pack: memset of the trailer failed");
+    const dim3 grid((unsigned)((F + 255) / 256));
+    if (transposed) hipLaunchKernelGGL(weight_colabs_kernel<true>, grid, dim3(256), 0, st, W, ldw, K, F, reinterpret_cast<unsigned int *>(trailer));
+    else hipLaunchKernelGGL(weight_colabs_kernel<false>, grid, dim3(256), 0, st, W, ldw, K, F, reinterpret_cast<unsigned int *>(trailer));
+    return check_launch("ggcn_weight_pack(trailer)");
+}
+
 }  // namespace
 
 size_t weight_pack_bytes(int K, int F, int precision)
@@ -372,8 +400,9 @@ size_t weight_pack_bytes(int K, int F, int precision)
     if (K <= 0 || F <= 0) return 0;
     const size_t stages = (size_t)bx3::round_up(K, bx3::BK) / bx3::BK;  // whole 32-deep stages
     const size_t n_tiles = (size_t)bx3::round_up(F, bx3::NT) / bx3::NT;
-    if (precision == GGCN_PREC_F16MX8 || precision == GGCN_PREC_F16) return n_tiles * stages * mx8::STAGE_PACK_BYTES;
-    if (precision == GGCN_PREC_F16MX6) return n_tiles * stages * mx6::STAGE_PACK_BYTES;
+    // (+ the trailer: max_f sum_k |w[k,f]|, the factor of the hidden-value bound of the one-launch layers, f16mx8_core.h)
+    if (precision == GGCN_PREC_F16MX8 || precision == GGCN_PREC_F16) return n_tiles * stages * mx8::STAGE_PACK_BYTES + mx8::PACK_TRAILER_BYTES;
+    if (precision == GGCN_PREC_F16MX6) return n_tiles * stages * mx6::STAGE_PACK_BYTES + mx8::PACK_TRAILER_BYTES;
     return n_tiles * stages * 2 * 2 * bx3::FRAG_BYTES;
 }
 
@@ -394,7 +423,8 @@ int weight_pack(const float *W, int64_t ldw, int K, int F, int precision, bool t
         else
             hipLaunchKernelGGL(weight_pack_mx8_kernel<false>, grid, dim3(64), 0, st, W, ldw, K, F, k_steps / 2,
                                static_cast<char *>(wpack));
-        return check_launch("ggcn_weight_pack(f16mx8)");
+        const int rc = check_launch("ggcn_weight_pack(f16mx8)");
+        return rc ? rc : pack_trailer(W, ldw, K, F, transposed, static_cast<char *>(wpack) + (size_t)n_tiles * (k_steps / 2) * mx8::STAGE_PACK_BYTES, st);
     }
     if (precision == GGCN_PREC_F16MX6) {
         const dim3 grid((unsigned)n_tiles, (unsigned)(k_steps / 2));
@@ -404,7 +434,8 @@ int weight_pack(const float *W, int64_t ldw, int K, int F, int precision, bool t
         else
             hipLaunchKernelGGL(weight_pack_mx6_kernel<false>, grid, dim3(64), 0, st, W, ldw, K, F, k_steps / 2,
                                static_cast<char *>(wpack));
-        return check_launch("ggcn_weight_pack(f16mx6)");
+        const int rc = check_launch("ggcn_weight_pack(f16mx6)");
+        return rc ? rc : pack_trailer(W, ldw, K, F, transposed, static_cast<char *>(wpack) + (size_t)n_tiles * (k_steps / 2) * mx6::STAGE_PACK_BYTES, st);
     }
     if (precision != GGCN_PREC_BF16X3) return fail(GGCN_EINVAL, "ggcn_weight_pack: precision %d has no packed image", precision);
     if (transposed)
@@ -448,17 +479,6 @@ int linear_packed_h(const void *X, int64_t ldx, const void *wpack, void *Y, int6
     return launch_linear<0, __half>(x, ldx, wpack, y, ldy, M, K, F, st);
 }
 
-// this translation unit's copy of the sticky f16mx8 range flag (f16mx8_core.h): OR it into *dst (device memory), clear on request
-__global__ void range_flag_linear_kernel(unsigned int *dst, int clear)
-{
-    const unsigned int v = mx8::g_range_flag;
-    if (v) atomicOr(dst, v);
-    if (clear) mx8::g_range_flag = 0u;
-}
-int range_flag_linear(unsigned int *dst, int clear, hipStream_t st)
-{
-    hipLaunchKernelGGL(range_flag_linear_kernel, dim3(1), dim3(1), 0, st, dst, clear);
-    return check_launch("ggcn_range_flag");
-}
+GGCN_RANGE_FLAG_TU(range_flag_linear)
 
 }  // namespace ggcn

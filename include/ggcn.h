@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 8
+#define GGCN_ABI_VERSION 9
 #define GGCN_MASK_MAX_T 256   /* largest graph the row-mask (one-launch) path takes */
 
 typedef void *ggcn_stream_t;
@@ -84,6 +84,9 @@ enum ggcn_precision {
 };
 
 int ggcn_abi_version(void);
+/* 1 when the library holds the experimental GGCN_PREC_F16MX6 form of the one-launch layer (csrc: make F16MX6=1); the
+ * product build does not (measured slower than GGCN_PREC_F16MX8) and refuses that precision with GGCN_EUNSUPPORTED. */
+int ggcn_has_f16mx6(void);
 const char *ggcn_last_error(void);
 
 /* ---- batched CSR from the reference's dense adjacency ---------------------
@@ -354,12 +357,21 @@ int ggcn_scores_head(const float *X, int64_t ldx, const float *aspect, int64_t l
 int ggcn_absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float *out, ggcn_stream_t stream);
 
 /* ---- sticky range flag of GGCN_PREC_F16MX8 (what makes it safe as a default) ----------------------
- * Every f16mx8 main loop (ggcn_linear, ggcn_layer_fused, ggcn_block_fused) keeps the running maximum of the |x| it
- * splits and sets a sticky library flag (per device) once a value reaches fp16's largest finite value 65504 (inf
- * included; a NaN input shows as NaN in the output instead); ggcn_weight_pack sets it for such a weight.  This call ORs
- * the flag into *flag (device memory, 4 bytes, zeroed by the caller) in stream order and, with clear != 0, resets it:
- * the caller copies the word to the host whenever it likes (the f16mx6 main loop sets the same flag) -- models/gcn.py:34 in fp32 has no such limit, so a set flag
- * means "re-run with GGCN_PREC_BF16X3".  Costs one v_max3 per two values in the split (< 1 % of the block). */
+ * models/gcn.py:34 multiplies in fp32 and has no range limit; f16mx8 meets the 1e-4 parity gate only inside a window, and
+ * says so when the data leaves it.  Every f16mx8 main loop (ggcn_linear, ggcn_layer_fused, ggcn_block_fused) keeps the
+ * running maximum of the |x| it splits (one v_max3 per two values: < 1 % of the block) and ORs these bits into a sticky
+ * per-device flag:
+ *   GGCN_RANGE_OVERFLOW  a value reached fp16's largest finite value 65504 (inf included; a NaN input shows as NaN in the
+ *                        output instead); ggcn_weight_pack sets it for such a weight.  Results are saturated.
+ *   GGCN_RANGE_WINDOW    a value left |x| <= 448, the range in which the fp8 correction terms are unsaturated: from there
+ *                        on the product has plain fp16 accuracy (2^-12 relative), outside the parity gate.
+ *   GGCN_RANGE_HIDDEN    the one-launch layer / block of graphs of <= 32 nodes (fp16 aggregation planes) could not rule
+ *                        out |hidden| >= 65504: max|x| * max_f sum_k |w[k,f]| (+ max |mid bias|) reached it (a sufficient
+ *                        bound from the weight image's trailer, not a detection: NaN is possible).
+ * Any bit means "re-run with GGCN_PREC_BF16X3" (full fp32 range).  This call ORs the flag into *flag (device memory,
+ * 4 bytes, zeroed by the caller) in stream order and, with clear != 0, resets it; the caller copies the word to the host
+ * whenever it likes.  (The experimental f16mx6 form sets OVERFLOW and HIDDEN; its block scales have no window.) */
+enum ggcn_range_bits { GGCN_RANGE_OVERFLOW = 1, GGCN_RANGE_WINDOW = 2, GGCN_RANGE_HIDDEN = 4 };
 int ggcn_range_flag(uint32_t *flag, int clear, ggcn_stream_t stream);
 
 /* ---- test hook: known garbage in every CU's LDS ---------------------------------------------------

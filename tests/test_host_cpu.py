@@ -44,7 +44,9 @@ def test_binding_covers_every_declared_symbol_and_abi_matches():
     assert lib.ggcn_weight_pack_bytes(768, 768, 0) == 768 * 768 * 2 * 2
     assert lib.ggcn_weight_pack_bytes(300, 300, 0) == 320 * 320 * 2 * 2
     # f16mx8: per (32 columns x 32 k) 2 KiB fp16 + 1 KiB fp8 (residual) + 256 B block scales
-    assert lib.ggcn_weight_pack_bytes(768, 768, 2) == 24 * 24 * 3328
+    # (+ a 16-byte trailer: max_f sum_k |w[k,f]|, the factor of the range flag's hidden-value bound)
+    assert lib.ggcn_weight_pack_bytes(768, 768, 2) == 24 * 24 * 3328 + 16
+    assert lib.ggcn_has_f16mx6() in (0, 1)
     assert lib.ggcn_csr_workspace_bytes(131072) == 128 * 4
     assert lib.ggcn_overlap_workspace_bytes(4096) == 4096 * 4
 
