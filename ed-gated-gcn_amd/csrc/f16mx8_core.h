@@ -108,7 +108,13 @@ struct Split4 {
     uint32_t h01, h23;  // fp16 pairs
     int l8, h8;         // 4 x fp8 of xl * 2^11, 4 x fp8 of x
 };
-__device__ __forceinline__ Split4 split4(float x0, float x1, float x2, float x3)
+// A register with unspecified contents, for free: the packed fp8 converts write HALF of their destination and keep the
+// other half (a tied "old" operand), and both halves get written here, so what the destination starts with is irrelevant --
+// but a seed that is still live elsewhere costs a v_mov, and so does a zero.  An empty asm "defines" a fresh register
+// without an instruction; the register allocator then places it wherever the result has to live (e.g. inside the
+// 8-register MX operand).  amax: the running maximum of |x| (range flag).
+__device__ __forceinline__ int undef_vgpr() { int r; asm volatile("" : "=v"(r)); return r; }
+__device__ __forceinline__ Split4 split4(float x0, float x1, float x2, float x3, float &amax)
 {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -121,13 +127,11 @@ __device__ __forceinline__ Split4 split4(float x0, float x1, float x2, float x3)
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(p1), "v"(x2));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(p1), "v"(x3));
     constexpr float inv = 1.0f / (float)(1 << XL_SHIFT);
-    // the packed converts write HALF of their destination and keep the other half: the value the destination
-    // starts with is irrelevant (both halves get written), so it is seeded with a register that dies here
-    // instead of a zero -- a zero costs one v_mov per destination, 16 of the ~90 VALU of a stage
-    s2 q = __builtin_bit_cast(s2, r0);
+    s2 q = __builtin_bit_cast(s2, undef_vgpr());
     q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, r0, r1, inv, false);
     q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, r2, r3, inv, true);
-    int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, __builtin_bit_cast(int, x0), false);
+    amax = amax3(x2, x3, amax3(x0, x1, amax));
+    int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, undef_vgpr(), false);
     h8 = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, h8, true);
     Split4 o;
     o.h01 = __builtin_bit_cast(uint32_t, p0);
@@ -158,12 +162,22 @@ __device__ __forceinline__ int q_lds_off(int row, int chunk)
 
 // RBLK: only the first `nblk` of this wavefront's four 32-row blocks hold nodes (wavefront-uniform run-time count: the second
 // row group of a 256-row graph slot, fused_layer.hip wide8) -- the MFMAs of the others are skipped, their rows stay zero.
-template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false>
+// BUF (needs AVEC and KFULL): X and W are read through buffer resources -- a base in SGPRs, a loop-invariant 32-bit lane
+// offset and a SCALAR offset per stage -- instead of 64-bit pointers in vector registers: the per-stage address arithmetic
+// (10 of ~90 VALU per stage: v_mad_i64_i32 / v_lshl_add_u64 per load) moves to the scalar unit.  bufx: the tile's X rows.
+template <typename AT>
+struct BufX {
+    const AT *base;                       // first row of the workgroup's tile (workgroup-uniform)
+    uint32_t bytes;                       // bytes of X from there to the end of the batch (reads beyond return zeros)
+    uint32_t off[Geom<AT>::NP];           // this lane's piece of pass i at stage 0, in bytes from base (padding rows: any valid piece)
+};
+template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false, bool BUF = false>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int stages_packed, int wm,
                                          int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN], int rot = 0, int nblk = 4,
-                                         float *amax_out = nullptr)
+                                         float *amax_out = nullptr, const BufX<AT> *bufx = nullptr)
 {
+    static_assert(!BUF || (AVEC && KFULL && sizeof(AT) == 4), "buffer loads: whole 16-byte pieces of fp32 rows");
     // rot: the K loop starts at stage `rot` and wraps around (same sum, another order).  The column
     // tiles of one row block run side by side on one XCD and read the same rows of X: started one
     // stage apart they find each other's lines in L2 instead of missing on them at the same moment.
@@ -177,10 +191,19 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     set_cvt_saturate(true);
     float amax = 0.0f;   // running max |x| of what this lane splits (range flag below)
 
+    constexpr int kRsrcFlags = 0x00020000;   // raw buffer, 32-bit elements (gfx9 family)
+    __amdgpu_buffer_rsrc_t xr, wr;
+    if constexpr (BUF) {
+        xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<AT *>(bufx->base), 0, (int)bufx->bytes, kRsrcFlags);
+        wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wpack), 0, 0x7fffffff, kRsrcFlags);
+    }
     float ra[NP][EPT];
     auto load_a_pass = [&](int i, int k0) {
         const int gk = k0 + s_k;
-        if constexpr (AVEC) {
+        if constexpr (BUF) {
+            const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, bufx->off[i], k0 * (int)sizeof(AT), 0));
+            ra[i][0] = t.x; ra[i][1] = t.y; ra[i][2] = t.z; ra[i][3] = t.w;
+        } else if constexpr (AVEC) {
             load16<AT>(arow[i] + ((KFULL || gk < K) ? gk : 0), ra[i]);
         } else {
 #pragma unroll
@@ -206,8 +229,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
                     x[c] = in ? x[c] : 0.0f;
                 }
             }
-            sp[q] = split4(x[0], x[1], x[2], x[3]);
-            amax = amax3(x[2], x[3], amax3(x[0], x[1], amax));
+            sp[q] = split4(x[0], x[1], x[2], x[3], amax);
         }
     };
     auto write_pass = [&](int buf, int i) {
@@ -233,22 +255,41 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         const int ntc = nt0 + j < n_tiles_total ? nt0 + j : n_tiles_total - 1;
         bbase[j] = wpack + (int64_t)ntc * stages_packed * STAGE_PACK_BYTES + lane * 16;
     }
+    uint32_t wtile[RN];   // BUF: uniform byte offsets of this wavefront's two column tiles inside the image
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int ntc = nt0 + j < n_tiles_total ? nt0 + j : n_tiles_total - 1;
+        wtile[j] = (uint32_t)ntc * (uint32_t)stages_packed * STAGE_PACK_BYTES;
+    }
+    const uint32_t lane16 = lane * 16, lane4 = lane * 4;
     auto load_bf = [&](int st, f16x8 (&b0)[RN], f16x8 (&b1)[RN]) {  // fp16 fragments of both k-steps of stage st
         st = st < stages_packed ? st : stages_packed - 1;
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
-            const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES;
-            b0[j] = *reinterpret_cast<const f16x8 *>(p);
-            b1[j] = *reinterpret_cast<const f16x8 *>(p + 1024);
+            if constexpr (BUF) {
+                const uint32_t so = wtile[j] + (uint32_t)st * STAGE_PACK_BYTES;
+                b0[j] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, so, 0));
+                b1[j] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, so + 1024, 0));
+            } else {
+                const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES;
+                b0[j] = *reinterpret_cast<const f16x8 *>(p);
+                b1[j] = *reinterpret_cast<const f16x8 *>(p + 1024);
+            }
         }
     };
     auto load_bq = [&](int st, i32x4 (&b)[RN], int (&sc)[RN]) {  // fp8 residual operand + scales of stage st
         st = st < stages_packed ? st : stages_packed - 1;
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
-            const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES;  // bbase already holds lane * 16
-            b[j] = *reinterpret_cast<const i32x4 *>(p + 2048);
-            sc[j] = *reinterpret_cast<const int *>(p + 3072 - lane * 12);  // + lane * 4
+            if constexpr (BUF) {
+                const uint32_t so = wtile[j] + (uint32_t)st * STAGE_PACK_BYTES;
+                b[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, so + 2048, 0));
+                sc[j] = __builtin_amdgcn_raw_buffer_load_b32(wr, lane4, so + 3072, 0);
+            } else {
+                const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES;  // bbase already holds lane * 16
+                b[j] = *reinterpret_cast<const i32x4 *>(p + 2048);
+                sc[j] = *reinterpret_cast<const int *>(p + 3072 - lane * 12);  // + lane * 4
+            }
         }
     };
     // fp8(wh * 2^s0) of this lane's 16 fp16 values (its two fragments): byte 1 of the scale dword is the
@@ -262,7 +303,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         for (int d = 0; d < 4; ++d) {
             const f16x8 &f = d < 2 ? f0 : f1;
             const int e = (d & 1) * 4;
-            s2 q = __builtin_bit_cast(s2, h2{f[e], f[e + 1]});   // seed: a register that dies here (see split4)
+            s2 q = __builtin_bit_cast(s2, undef_vgpr());   // (seeding with the fragment registers cost 3 v_mov per tile: the operand is a tuple)
             q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, h2{f[e], f[e + 1]}, inv, false);
             q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, h2{f[e + 2], f[e + 3]}, inv, true);
             o[d] = __builtin_bit_cast(int, q);

@@ -273,6 +273,48 @@ __device__ __forceinline__ void fused_range_verdict(float amax, const char *wpac
     mx8::range_verdict(amax, bw, fmaxf(fmaxf(mm.x, mm.y), fmaxf(mm.z, mm.w)), window);
 }
 
+// plain v_max / v_min (fmaxf first quiets a possible signalling NaN of an operand the compiler cannot prove canonical -- after a
+// lane exchange, say: one extra instruction per operand)
+__device__ __forceinline__ float vmax_raw(float x, float y) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
+__device__ __forceinline__ float vmin_raw(float x, float y) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }
+
+// The two lane halves hold different rows of the same column.  max over both halves AND min over both halves, both
+// delivered to lanes 0-31, in 2 swaps + 2 VALU and no copies: v_permlane32_swap exchanges the upper half of its first
+// operand with the lower half of its second, so swap(vmax, vmin) leaves {vmax.lo | vmin.lo}, {vmax.hi | vmin.hi}: their
+// max is the full maximum in lanes 0-31, their min the full minimum in lanes 32-63; a second swap brings that one down.
+// (The earlier form copied each value, swapped it with itself and canonicalised both sides: ~14 instructions.)
+__device__ __forceinline__ void meet_halves(float &vmax, float &vmin)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(vmax), __float_as_uint(vmin), false, false);
+    const float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
+    const float m = vmax_raw(a, b), n = vmin_raw(a, b);
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(n), __float_as_uint(a), false, false);
+    vmax = m;                            // lanes 0-31
+    vmin = __uint_as_float(q[1]);        // lanes 0-31: n of lanes 32-63
+}
+
+// sum over the 64 lanes, delivered to lane 0, without an LDS round trip per step (a ds_bpermute butterfly is six dependent
+// LDS operations, each waited for): four DPP adds leave every 16-lane row's sum in all of its lanes, lane 0 adds the other
+// three rows' from scalar registers.  Fixed order: deterministic.
+__device__ __forceinline__ float wave_sum_to_lane0(float v)
+{
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const float r1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
+    const float r2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+    const float r3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
+    return (v + r1) + (r2 + r3);
+}
+
+// a global array behind a buffer resource: stores take a 32-bit lane offset and a scalar offset instead of a 64-bit address
+// per lane (v_ashrrev + v_lshl_add_u64 per store, a sixth of the epilogue's VALU instructions)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(void *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7fffffff, 0x00020000);
+}
+
 // ---- the epilogue of one wavefront: its 4 graphs x RN column tiles ------------------------------------------------
 // MID: the block's second layer through W12 (two aggregations with the `mid` bias in between); OUT: the [N,F] output is
 // stored.  Per graph: both column tiles are split, multiplied by the adjacency and finished side by side, so that one
@@ -424,22 +466,22 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
                 pa = fmaxf(pmax_a, upper_half_to_lower(pmax_a));
                 pb = fmaxf(pmax_b, upper_half_to_lower(pmax_b));
             } else {
-                vmax = fmaxf(vmax, upper_half_to_lower(vmax));
-                vmin = fminf(vmin, upper_half_to_lower(vmin));
+                meet_halves(vmax, vmin);
                 const float ga = vga[j], gb = vgb[j];
                 pa = ga * (ga >= 0.0f ? vmax : vmin);
                 pb = gb * (gb >= 0.0f ? vmax : vmin);
             }
             if (h == 0 && col_ok[j]) {
-                if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
-                if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
+                // pooled rows through buffer resources: lane offset = column, scalar offset = graph row (the graph's F floats
+                // from the array's base: rebuilt per graph on the scalar unit, so B * F may exceed 32 bits)
+                if (pool_a) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pa), out_rsrc(pool_a + (int64_t)g * F), 4 * gn, 0, 0);
+                if (pool_b) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pb), out_rsrc(pool_b + (int64_t)g * F), 4 * gn, 0, 0);
                 dot = fmaf(pa, pb, dot);
             }
         }
-        if (ov_partial && nt0 < n_tiles_total) {  // fixed butterfly order; lanes with h = 1 hold 0
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
-            if (lane == 0) ov_partial[(int64_t)g * ((F + 63) / 64) + (nt0 >> 1)] = dot;
+        if (ov_partial && nt0 < n_tiles_total) {  // fixed order; lanes with h = 1 hold 0
+            const float tot = wave_sum_to_lane0(dot);
+            if (lane == 0) ov_partial[(int64_t)g * ((F + 63) / 64) + (nt0 >> 1)] = tot;
         }
         if constexpr (vst) {
             // rows of 64 columns (both column tiles of this wavefront) leave as 16 B per lane: one
@@ -448,12 +490,17 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
             __builtin_amdgcn_wave_barrier();
             const int colq = (lane & 15) * 4;
             const int gcol = nt0 * NT + colq;
-            float *gbase = out + ((int64_t)g * T) * ldo + gcol;
+            // the graph's rows behind a buffer resource (base rebuilt per graph on the scalar unit): lane offset = this
+            // lane's row of the first group + its columns, scalar offset = 4 rows per step -- no 64-bit lane arithmetic
+            const __amdgpu_buffer_rsrc_t orsrc = out_rsrc(out + ((int64_t)g * T) * ldo);
+            const int voff = ((lane >> 4) * ldo + gcol) * 4;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = 4 * it + (lane >> 4);
                 const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 64 + (colq ^ (32 * ((row >> 2) & 1)))]);
-                if ((FULLT || row < T) && gcol < F && !((GGCN_LAB_EPI) & 1)) store_out4(gbase + row * ldo, v4);   // (GGCN_LAB_EPI 1: timing build without the stores)
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                if ((FULLT || row < T) && gcol < F && !((GGCN_LAB_EPI) & 1))   // (GGCN_LAB_EPI 1: timing build without the stores)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), orsrc, voff, 4 * it * ldo * 4, 0);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -129,7 +129,24 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
         bx3::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, a.k_steps, wm, nt0, n_tiles_total, lds, acc);
     else {
         float amax;
-        mx8::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc, 0, 4, &amax);
+        // fast shapes (16-byte rows, K % 32 == 0): buffer loads -- the tile's X rows behind one resource (the launcher
+        // checked that 128 rows of ldx floats stay below 2 GiB), lane offsets fixed before the loop
+        constexpr bool BUF = AVEC && KFULL;
+        mx8::BufX<float> bx;
+        if constexpr (BUF) {
+            const int64_t row0 = (int64_t)gt0 * T;                               // first node of the tile: always a real one
+            const int64_t left = ((int64_t)B * T - row0) * a.ldx * 4;
+            bx.base = a.X + row0 * a.ldx;
+            bx.bytes = (uint32_t)(left < 0x7fffffff ? left : 0x7fffffff);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int row = stage_row<float>(i);
+                const int64_t rel = avalid[i] ? (int64_t)(row >> 5) * T + (row & 31) : 0;   // padding rows read row 0 (zeroed at the split)
+                bx.off[i] = (uint32_t)((rel * a.ldx + (tid % Geom<float>::TPR) * Geom<float>::EPT) * 4);
+            }
+        }
+        mx8::mainloop<float, AVEC, KFULL, !FULLT, false, BUF>(arow, avalid, wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc, 0, 4,
+                                                             &amax, &bx);
         fused_range_verdict<kLdsBytes>(amax, wpack, (int64_t)n_tiles_total * (a.k_steps / 2) * mx8::STAGE_PACK_BYTES, lds, true);
     }
     GGCN_TRACE(5);
@@ -252,11 +269,13 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
             if ((int64_t)a.T * lp.ldo >= (int64_t)INT32_MAX)
                 return fail(GGCN_EUNSUPPORTED, "%s: T*ldo does not fit 32-bit offsets", who);
             any_out = true;
-            vst = vst && (a.F % 4 == 0) && (lp.ldo % 4 == 0) && aligned16(lp.out);
+            // (the 16-byte row stores address a graph's rows with 32-bit byte offsets from its first row)
+            vst = vst && (a.F % 4 == 0) && (lp.ldo % 4 == 0) && aligned16(lp.out) && (int64_t)a.T * lp.ldo * 4 < ((int64_t)1 << 31);
         }
     }
     vst = vst && any_out;
-    const bool avec = (a.K % 4 == 0) && (a.ldx % 4 == 0) && aligned16(a.X);
+    // (the fast shapes address a tile's 128 rows with 32-bit byte offsets from its first row: buffer loads)
+    const bool avec = (a.K % 4 == 0) && (a.ldx % 4 == 0) && aligned16(a.X) && (int64_t)a.ldx * 4 * 129 < ((int64_t)1 << 31);
     const bool kfull = (a.K % BK == 0);
     a.k_steps = round_up(a.K, BK) / KSTEP;
     a.n_wg = (a.F + BN - 1) / BN;
