@@ -50,7 +50,17 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int STAGE_PACK_BYTES = 2 * 1024 + 64 * 16 + 64 * 4;  // 3328
+// GGCN_WH8_STORED (default 0): 1 = the image also holds fp8(wh * 2^s0), the other half of the MX operand (1 KiB more per
+// record: W traffic through L2 +31 %) instead of every lane converting it from its fp16 fragments in the loop (16
+// v_cvt_scalef32_pk_fp8_f16 + 4 VALU per stage).  Bit-identical results; measured twice: round 2 had the in-loop form 2 %
+// faster, round 4 (the loop's other VALU work cut by a quarter, the ladder pricing the converts at 29 us) block 624 vs
+// 622 us, one layer 355 vs 344, plain linear 335 vs 324 -- W's path from L2 is the scarcer resource.
+#ifndef GGCN_WH8_STORED
+#define GGCN_WH8_STORED 0
+#endif
+constexpr int kWh8Bytes = GGCN_WH8_STORED ? 64 * 16 : 0;
+constexpr int kOffWl8 = 2 * 1024, kOffWh8 = kOffWl8 + 64 * 16, kOffScales = kOffWh8 + kWh8Bytes;
+constexpr int STAGE_PACK_BYTES = kOffScales + 64 * 4;  // 3328 (4352 with the stored wh8)
 constexpr int XL_SHIFT = 11;                                    // xl is stored as xl * 2^11
 constexpr int SCALE_XL = 127 - XL_SHIFT, SCALE_XH = 127;
 
@@ -171,6 +181,21 @@ struct BufX {
     uint32_t bytes;                       // bytes of X from there to the end of the batch (reads beyond return zeros)
     uint32_t off[Geom<AT>::NP];           // this lane's piece of pass i at stage 0, in bytes from base (padding rows: any valid piece)
 };
+// X [total_rows, ldx]; the tile starts at base_row (a real row); rel[i] = this lane's row of pass i relative to it (padding
+// rows: 0).  The launchers admit the buffer path only when 257 rows of ldx elements stay below 2 GiB.
+template <typename AT>
+__device__ __forceinline__ BufX<AT> make_bufx(const AT *X, int64_t ldx, int64_t base_row, int64_t total_rows,
+                                              const int (&rel)[Geom<AT>::NP], int tid)
+{
+    BufX<AT> b;
+    const int64_t left = (total_rows - base_row) * ldx * (int64_t)sizeof(AT);
+    b.base = X + base_row * ldx;
+    b.bytes = (uint32_t)(left < 0x7fffffff ? left : 0x7fffffff);
+#pragma unroll
+    for (int i = 0; i < Geom<AT>::NP; ++i)
+        b.off[i] = (uint32_t)(((int64_t)rel[i] * ldx + (tid % Geom<AT>::TPR) * Geom<AT>::EPT) * (int64_t)sizeof(AT));
+    return b;
+}
 template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false, bool BUF = false>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int stages_packed, int wm,
@@ -283,13 +308,21 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         for (int j = 0; j < RN; ++j) {
             if constexpr (BUF) {
                 const uint32_t so = wtile[j] + (uint32_t)st * STAGE_PACK_BYTES;
-                b[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, so + 2048, 0));
-                sc[j] = __builtin_amdgcn_raw_buffer_load_b32(wr, lane4, so + 3072, 0);
+                b[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, so + kOffWl8, 0));
+                sc[j] = __builtin_amdgcn_raw_buffer_load_b32(wr, lane4, so + kOffScales, 0);
             } else {
                 const char *p = bbase[j] + (int64_t)st * STAGE_PACK_BYTES;  // bbase already holds lane * 16
-                b[j] = *reinterpret_cast<const i32x4 *>(p + 2048);
-                sc[j] = *reinterpret_cast<const int *>(p + 3072 - lane * 12);  // + lane * 4
+                b[j] = *reinterpret_cast<const i32x4 *>(p + kOffWl8);
+                sc[j] = *reinterpret_cast<const int *>(p + kOffScales - lane * 12);  // + lane * 4
             }
+        }
+    };
+    auto load_wh8 = [&](int st, i32x4 (&b)[RN]) {   // GGCN_WH8_STORED: fp8(wh * 2^s0) of stage st as packed
+        st = st < stages_packed ? st : stages_packed - 1;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            if constexpr (BUF) b[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, wtile[j] + (uint32_t)st * STAGE_PACK_BYTES + kOffWh8, 0));
+            else b[j] = *reinterpret_cast<const i32x4 *>(bbase[j] + (int64_t)st * STAGE_PACK_BYTES + kOffWh8);
         }
     };
     // fp8(wh * 2^s0) of this lane's 16 fp16 values (its two fragments): byte 1 of the scale dword is the
@@ -341,6 +374,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 
     f16x8 b0[RN], b1[RN];
     i32x4 bq[RN];  // fp8(wl) of the stage
+    i32x4 bw[RN];  // fp8(wh) of the stage (GGCN_WH8_STORED)
     int sq[RN];
     const int stages = (K + BK - 1) / BK;
 
@@ -378,9 +412,10 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         read_h(0, 0, lab_h);
         read_q(0, 0, lab_q);
         load_bq(kstage(0), bq, sq);
+        if constexpr (GGCN_WH8_STORED) load_wh8(kstage(0), bw);
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
-            const i32x4 w = wh8_of(b0[j], b1[j], sq[j]);
+            const i32x4 w = GGCN_WH8_STORED ? bw[j] : wh8_of(b0[j], b1[j], sq[j]);
             lab_bm[j] = i32x8{w[0], w[1], w[2], w[3], bq[j][0], bq[j][1], bq[j][2], bq[j][3]};
         }
     }
@@ -391,7 +426,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         f16x8 ah[2][2];
         i32x8 aq[2];
         if GGCN_ON(8) read_h(buf, 0, ah[0]); else { ah[0][0] = lab_h[0]; ah[0][1] = lab_h[1]; }
-        if GGCN_ON(16) load_bq(kstage(st), bq, sq);
+        if GGCN_ON(16) { load_bq(kstage(st), bq, sq); if constexpr (GGCN_WH8_STORED) load_wh8(kstage(st), bw); }
         GGCN_SB();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -426,7 +461,9 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         i32x8 bm[RN];
         auto make_bm = [&](int j) {
             if GGCN_ON(32) {
-                const i32x4 w = wh8_of(b0[j], b1[j], sq[j]);
+                i32x4 w;
+                if constexpr (GGCN_WH8_STORED) w = bw[j];
+                else w = wh8_of(b0[j], b1[j], sq[j]);
                 bm[j] = i32x8{w[0], w[1], w[2], w[3], bq[j][0], bq[j][1], bq[j][2], bq[j][3]};
             } else {
                 bm[j] = lab_bm[j];

@@ -134,16 +134,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
         constexpr bool BUF = AVEC && KFULL;
         mx8::BufX<float> bx;
         if constexpr (BUF) {
-            const int64_t row0 = (int64_t)gt0 * T;                               // first node of the tile: always a real one
-            const int64_t left = ((int64_t)B * T - row0) * a.ldx * 4;
-            bx.base = a.X + row0 * a.ldx;
-            bx.bytes = (uint32_t)(left < 0x7fffffff ? left : 0x7fffffff);
+            int rel[NP];
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int row = stage_row<float>(i);
-                const int64_t rel = avalid[i] ? (int64_t)(row >> 5) * T + (row & 31) : 0;   // padding rows read row 0 (zeroed at the split)
-                bx.off[i] = (uint32_t)((rel * a.ldx + (tid % Geom<float>::TPR) * Geom<float>::EPT) * 4);
+                rel[i] = avalid[i] ? (row >> 5) * T + (row & 31) : 0;   // padding rows read row 0 (zeroed at the split)
             }
+            bx = mx8::make_bufx<float>(a.X, a.ldx, (int64_t)gt0 * T, (int64_t)B * T, rel, tid);   // the tile's first node is always a real one
         }
         mx8::mainloop<float, AVEC, KFULL, !FULLT, false, BUF>(arow, avalid, wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc, 0, 4,
                                                              &amax, &bx);
@@ -275,7 +272,7 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
     }
     vst = vst && any_out;
     // (the fast shapes address a tile's 128 rows with 32-bit byte offsets from its first row: buffer loads)
-    const bool avec = (a.K % 4 == 0) && (a.ldx % 4 == 0) && aligned16(a.X) && (int64_t)a.ldx * 4 * 129 < ((int64_t)1 << 31);
+    const bool avec = (a.K % 4 == 0) && (a.ldx % 4 == 0) && aligned16(a.X) && (int64_t)a.ldx * 4 * 257 < ((int64_t)1 << 31);
     const bool kfull = (a.K % BK == 0);
     a.k_steps = round_up(a.K, BK) / KSTEP;
     a.n_wg = (a.F + BN - 1) / BN;

@@ -65,8 +65,21 @@ __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_f
         f32x16 acc[4][RN];
         if constexpr (SCH == 0)
             bx3::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps, wm, nt0, n_tiles_total, lds, acc);
-        else
-            mx8::mainloop<float, AVEC, KFULL, true>(arow, avalid, lp.wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
+        else {
+            constexpr bool BUF = AVEC && KFULL;   // buffer loads (f16mx8_core.h): offsets from the workgroup's first graph
+            mx8::BufX<float> bx;
+            if constexpr (BUF) {
+                int rel[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const int row = stage_row<float>(i) + 128 * hh;
+                    rel[i] = avalid[i] ? (row / S) * T + row % S : 0;
+                }
+                bx = mx8::make_bufx<float>(a.X, a.ldx, (int64_t)g0 * T, (int64_t)B * T, rel, tid);
+            }
+            mx8::mainloop<float, AVEC, KFULL, true, false, BUF>(arow, avalid, lp.wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc, 0, 4,
+                                                                 nullptr, &bx);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

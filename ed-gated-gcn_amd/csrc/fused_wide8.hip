@@ -81,8 +81,21 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
         const int nblk = rows_here >= 128 ? 4 : rows_here <= 0 ? 0 : (rows_here + 31) >> 5;
         if constexpr (SCH == 0)
             bx3::mainloop<float, AVEC, KFULL, true, true>(arow, avalid, lp.wpack, K, a.k_steps, 0, nt0, n_tiles_total, stage, acc, nblk);
-        else
-            mx8::mainloop<float, AVEC, KFULL, true, true>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc, 0, nblk);
+        else {
+            constexpr bool BUF = AVEC && KFULL;   // buffer loads (f16mx8_core.h): offsets from the graph's first node
+            mx8::BufX<float> bx;
+            if constexpr (BUF) {
+                int rel[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const int r = stage_row<float>(i) + 128 * rg;
+                    rel[i] = avalid[i] ? r : 0;
+                }
+                bx = mx8::make_bufx<float>(a.X, a.ldx, (int64_t)g * T, (int64_t)B * T, rel, tid & (kThreads - 1));
+            }
+            mx8::mainloop<float, AVEC, KFULL, true, true, BUF>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc, 0, nblk,
+                                                                nullptr, &bx);
+        }
     }
     if constexpr (GGCN_LAB_WIDE8_DENSE) {
     // every accumulator tile -> its two bf16 planes (B-operand fragments of the aggregation MFMAs), in place

@@ -118,12 +118,22 @@ __global__ __launch_bounds__(64) void weight_pack_mx8_kernel(const float *__rest
         b8 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wl[4 * t + 2], s1), ldexpf(wl[4 * t + 3], s1), b8, true);
         q[t] = b8;
     }
-    int *mxp = reinterpret_cast<int *>(base + 2048 + lane * 16);
+    int *mxp = reinterpret_cast<int *>(base + mx8::kOffWl8 + lane * 16);
 #pragma unroll
     for (int t = 0; t < 4; ++t) mxp[t] = q[t];
+    if constexpr (GGCN_WH8_STORED) {   // block 0 = fp8(wh * 2^s0), same byte <-> k map (what the main loop used to convert per stage)
+        int *whp = reinterpret_cast<int *>(base + mx8::kOffWh8 + lane * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int b8 = 0;
+            b8 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wh[4 * t], s0), ldexpf(wh[4 * t + 1], s0), b8, false);
+            b8 = __builtin_amdgcn_cvt_pk_fp8_f32(ldexpf(wh[4 * t + 2], s0), ldexpf(wh[4 * t + 3], s0), b8, true);
+            whp[t] = b8;
+        }
+    }
     // E8M0 (value = 2^(byte-127)): byte 0 = the scale of this lane's block for the MFMA (lane c: block 0,
     // lane c + 32: block 1), byte 1 = the scale of block 0 for the in-loop fp16 -> fp8 conversion
-    *reinterpret_cast<int *>(base + 3072 + lane * 4) = ((127 - s0) << 8) | (127 - (h ? s1 : s0));
+    *reinterpret_cast<int *>(base + mx8::kOffScales + lane * 4) = ((127 - s0) << 8) | (127 - (h ? s1 : s0));
 }
 
 // ---- W -> f16mx6 image (f16mx6_core.h): per (32-column tile, 32-deep stage) [f16 frag k-step 0][k-step 1]
@@ -214,8 +224,20 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_split_kernel(
     f32x16 acc[4][RN];
     if constexpr (SCH == 0)
         bx3::mainloop<ET, AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps, wm, nt0, n_tiles_total, lds, acc);
-    else
-        mx8::mainloop<ET, AVEC, KFULL, false>(arow, avalid, wpack, K, k_steps / 2, wm, nt0, n_tiles_total, lds, acc);
+    else {
+        constexpr bool BUF = AVEC && KFULL && sizeof(ET) == 4;   // buffer loads (f16mx8_core.h): offsets from the tile's first row
+        mx8::BufX<ET> bx;
+        if constexpr (BUF) {
+            int rel[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int64_t gm = m0 + stage_row<ET>(i);
+                rel[i] = (int)((gm < M ? gm : M - 1) - m0);
+            }
+            bx = mx8::make_bufx<ET>(X, ldx, m0, M, rel, tid);
+        }
+        mx8::mainloop<ET, AVEC, KFULL, false, false, BUF>(arow, avalid, wpack, K, k_steps / 2, wm, nt0, n_tiles_total, lds, acc, 0, 4, nullptr, &bx);
+    }
 
     const bool full_rows = m0 + BM <= M;  // workgroup-uniform: the row guard only exists in the last tile
     if constexpr (VST) {
@@ -345,7 +367,8 @@ int launch_linear(const ET *X, int64_t ldx, const void *wpack, ET *Y, int64_t ld
     if (!wpack) return fail(GGCN_EINVAL, "ggcn_linear(bf16x3): wpack is NULL (call ggcn_weight_pack first)");
     if (!aligned16(wpack)) return fail(GGCN_EINVAL, "ggcn_linear(bf16x3): wpack must be 16-byte aligned");
     constexpr int EPT = Geom<ET>::EPT;
-    const bool avec = (K % EPT == 0) && (ldx % EPT == 0) && aligned16(X);
+    // (the fast shapes address a tile's 128 rows with 32-bit byte offsets from its first row: buffer loads)
+    const bool avec = (K % EPT == 0) && (ldx % EPT == 0) && aligned16(X) && (int64_t)ldx * (int64_t)sizeof(ET) * 257 < ((int64_t)1 << 31);
     const bool kfull = (K % BK == 0);
     const int k_steps = round_up(K, BK) / KSTEP;
     const int64_t m_tiles = (M + BM - 1) / BM;
