@@ -196,13 +196,18 @@ __device__ __forceinline__ BufX<AT> make_bufx(const AT *X, int64_t ldx, int64_t 
         b.off[i] = (uint32_t)(((int64_t)rel[i] * ldx + (tid % Geom<AT>::TPR) * Geom<AT>::EPT) * (int64_t)sizeof(AT));
     return b;
 }
-template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false, bool BUF = false>
+// NB (fp32 rows: one staging pass = one 32-row block): only the first NB of this wavefront's four blocks exist at all -- the
+// staging passes, fragment reads and MFMAs of the others are not compiled in (the second row group of a 129..224-node graph
+// in a 256-row slot, fused_wide8.hip): their LDS rows are never written or read, their accumulators stay zero.
+template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false, bool BUF = false, int NB = 4>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int stages_packed, int wm,
                                          int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN], int rot = 0, int nblk = 4,
                                          float *amax_out = nullptr, const BufX<AT> *bufx = nullptr)
 {
     static_assert(!BUF || (AVEC && KFULL && sizeof(AT) == 4), "buffer loads: whole 16-byte pieces of fp32 rows");
+    static_assert(NB >= 1 && NB <= 4 && (NB == 4 || (sizeof(AT) == 4 && !RBLK)), "NB < 4: fp32 rows (pass i = block i), no run-time count");
+    constexpr int NPL = Geom<AT>::NP < NB ? Geom<AT>::NP : NB;   // live staging passes
     // rot: the K loop starts at stage `rot` and wraps around (same sum, another order).  The column
     // tiles of one row block run side by side on one XCD and read the same rows of X: started one
     // stage apart they find each other's lines in L2 instead of missing on them at the same moment.
@@ -385,15 +390,15 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         return s >= stages ? s - stages : s;
     };
 #pragma unroll
-    for (int p = 0; p < NP; ++p) load_a_pass(p, kstage(0) * BK);
+    for (int p = 0; p < NPL; ++p) load_a_pass(p, kstage(0) * BK);
     load_bf(kstage(0), b0, b1);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
+    for (int p = 0; p < NPL; ++p) {
         split_pass(p, kstage(0) * BK);
         write_pass(0, p);
     }
 #pragma unroll
-    for (int p = 0; p < NP; ++p) load_a_pass(p, kstage(1) * BK);
+    for (int p = 0; p < NPL; ++p) load_a_pass(p, kstage(1) * BK);
     __syncthreads();
 
     // One stage = 8 slots of 128 matrix-pipe cycles each; the source order below IS the issue order
@@ -429,12 +434,12 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         if GGCN_ON(16) { load_bq(kstage(st), bq, sq); if constexpr (GGCN_WH8_STORED) load_wh8(kstage(st), bw); }
         GGCN_SB();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NB; ++i) {
             if GGCN_ON(8) {
-                if (i < 3) read_h(buf, i + 1, ah[(i + 1) & 1]);
+                if (i < NB - 1) read_h(buf, i + 1, ah[(i + 1) & 1]);
                 else read_q(buf, 0, aq[0]);
             } else {
-                if (i < 3) { ah[(i + 1) & 1][0] = lab_h[0]; ah[(i + 1) & 1][1] = lab_h[1]; }
+                if (i < NB - 1) { ah[(i + 1) & 1][0] = lab_h[0]; ah[(i + 1) & 1][1] = lab_h[1]; }
                 else aq[0] = lab_q;
             }
             GGCN_SB();
@@ -473,9 +478,9 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         if constexpr (!(GGCN_LAB_WH8)) make_bm(1);
         GGCN_SB();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if GGCN_ON(8) { if (i < 3) read_q(buf, i + 1, aq[(i + 1) & 1]); }
-            else { if (i < 3) aq[(i + 1) & 1] = lab_q; }
+        for (int i = 0; i < NB; ++i) {
+            if GGCN_ON(8) { if (i < NB - 1) read_q(buf, i + 1, aq[(i + 1) & 1]); }
+            else { if (i < NB - 1) aq[(i + 1) & 1] = lab_q; }
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[0], acc[i][0], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[0]);
             GGCN_SB();

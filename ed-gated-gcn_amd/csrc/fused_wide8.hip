@@ -93,8 +93,19 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                 }
                 bx = mx8::make_bufx<float>(a.X, a.ldx, (int64_t)g * T, (int64_t)B * T, rel, tid & (kThreads - 1));
             }
-            mx8::mainloop<float, AVEC, KFULL, true, true, BUF>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc, 0, nblk,
-                                                                nullptr, &bx);
+            // The second row group of a graph of 129..224 nodes holds 1-3 blocks of real rows: its own instantiation of the
+            // loop without the others' staging passes, fragment reads and MFMAs (the two groups meet at the same barriers
+            // from different code; a run-time count could only skip the MFMAs -- guarding the staging passes broke the
+            // issue order the loop lives on).  The SIMD such a wavefront shares with a first-group wavefront is mostly the
+            // latter's: 512 x 129 x 768 ... (tools/wide_timing.py)
+            if (rg == 1 && nblk == 1)
+                mx8::mainloop<float, AVEC, KFULL, true, false, BUF, 1>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc, 0, 4, nullptr, &bx);
+            else if (rg == 1 && nblk == 2)
+                mx8::mainloop<float, AVEC, KFULL, true, false, BUF, 2>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc, 0, 4, nullptr, &bx);
+            else if (rg == 1 && nblk == 3)
+                mx8::mainloop<float, AVEC, KFULL, true, false, BUF, 3>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc, 0, 4, nullptr, &bx);
+            else
+                mx8::mainloop<float, AVEC, KFULL, true, false, BUF, 4>(arow, avalid, lp.wpack, K, a.k_steps / 2, 0, nt0, n_tiles_total, stage, acc, 0, 4, nullptr, &bx);
         }
     }
     if constexpr (GGCN_LAB_WIDE8_DENSE) {
@@ -376,19 +387,23 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
         const int col0 = (nt0 + j) * NT + 4 * cl;   // this lane's four columns
         // degree, reciprocal and the first 8 list entries of a row step are read one step ahead: a step is then ONE
         // dependent LDS round trip (the source rows) instead of two
-        int deg_n = s_deg[128 * rg + q8];
-        float inv_n = s_inv[128 * rg + q8];
-        uint4 idq_n = *reinterpret_cast<const uint4 *>(s_ids + (128 * rg + q8) * kW8Cap);
+        // The two wavefronts of a column group take the row steps (8 rows each) ALTERNATELY -- step 2 it + rg -- whatever row
+        // group their accumulators came from: a 129-node graph is 17 steps, 9 and 8 of them instead of 16 and 1 (the tile in
+        // LDS holds every row; the pools meet in LDS anyway).
+        int deg_n = s_deg[8 * rg + q8];
+        float inv_n = s_inv[8 * rg + q8];
+        uint4 idq_n = *reinterpret_cast<const uint4 *>(s_ids + (8 * rg + q8) * kW8Cap);
         for (int it = 0; it < n_steps; ++it) {
-            if (128 * rg + 8 * it >= T) break;   // wavefront-uniform: only padding rows from here on
-            const int row = 128 * rg + 8 * it + q8;
+            const int step = 2 * it + rg;
+            if (8 * step >= T) break;   // wavefront-uniform: only padding rows from here on
+            const int row = 8 * step + q8;
             const int deg = deg_n;
             const float inv = inv_n;
             const uint4 idq0 = idq_n;
-            if (it + 1 < 16) {   // (rows 248..255 of the second row group exist in LDS: the lists cover all 256 slots)
-                deg_n = s_deg[row + 8];
-                inv_n = s_inv[row + 8];
-                idq_n = *reinterpret_cast<const uint4 *>(s_ids + (row + 8) * kW8Cap);
+            if (it + 1 < 16) {   // (the lists cover all 256 row slots)
+                deg_n = s_deg[row + 16];
+                inv_n = s_inv[row + 16];
+                idq_n = *reinterpret_cast<const uint4 *>(s_ids + (row + 16) * kW8Cap);
             }
             float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             auto pass = [&](const uint4 &idq, int e0) {

@@ -298,7 +298,7 @@ class GraphConvolution(nn.Module):
                                             or any(g is not None and g.requires_grad for g in gates))
 
     WIDE_AUTO_MIN_T = 193     # graphs of 193..256 nodes fill >= 75 % of the 256-row slot of the eight-wavefront kernel
-    WIDE_AUTO_MIN_T_FULL = 161   # 161..192 nodes: only batches that fill whole rounds of workgroups (one per CU)
+    WIDE_AUTO_MIN_T_FULL = {"f16mx8": 129, "bf16x3": 161}   # shorter graphs: only batches that fill whole rounds of workgroups (one per CU)
     WIDE_AUTO_FILL = 0.9
 
     def takes_fused_path(self, text, csr):
@@ -306,11 +306,14 @@ class GraphConvolution(nn.Module):
         nodes (row masks exist up to 256), 0/1 adjacency, float32 features, a split-precision linear.  Beyond
         ``fused_max_t`` (128 by default), graphs of 193..256 nodes (ACE cased: ``ORI_ML = 231``, ``constant.py:267``) take
         the eight-wavefront form (``layer_fused_wide8_kernel``: one workgroup per graph x 256 columns) on their own: it
-        wins over linear + aggregate by 20 % on large batches (512 x 231 x 768: 399 vs 498 us) and ties on small or ragged
-        ones (128 x 231 x 768: 132 vs 132 us).  Graphs of 161..192 nodes (the second row group skips the MFMAs of its
-        empty 32-row blocks) win when the workgroups fill whole rounds (512 x 176 x 768: 362 vs 391 us; 128 x 176 x 768,
-        1.5 rounds: 120 vs 102) and take it only then; shorter graphs leave too much of the 256-row slot empty
-        (512 x 129 x 768: 337 vs 294 us) and keep the two launches (``tools/wide_timing.py``)."""
+        wins over linear + aggregate by 15 % on large batches (512 x 231 x 768: 418 vs 492 us) and ties on small ones
+        (128 x 231 x 768: 128 vs 134 us).  Shorter graphs leave part of the 256-row slot empty: the second row group runs
+        a main loop compiled for its 1-3 live 32-row blocks (f16mx8) and both row groups share the epilogue's row steps,
+        which wins when the workgroups fill whole rounds (512 x 129 x 768: 296 vs 302 us, 512 x 160: 324 vs 346, 512 x 192:
+        349 vs 416) and loses on a fraction of a round (128 x 129 x 768: 89 vs 79 us, 128 x 160: 95 vs 90) -- those keep the two
+        launches (``tools/wide_timing.py``).  The choice depends on the batch size and the device's CU count, and the two
+        paths sum in different orders (both inside the parity gate): ``fused_max_t = 256`` (always one launch) or
+        ``fused = False`` (never) pin it where bit-reproducibility across batch sizes matters."""
         if not (self.fused and self.precision in _capi.PACKED and csr.rowmask is not None and csr.is_binary
                 and text.dtype == torch.float32):
             return False
@@ -320,7 +323,7 @@ class GraphConvolution(nn.Module):
             return False
         if csr.T >= self.WIDE_AUTO_MIN_T:
             return True
-        if csr.T < self.WIDE_AUTO_MIN_T_FULL or not text.is_cuda:
+        if csr.T < self.WIDE_AUTO_MIN_T_FULL.get(self.precision, 161) or not text.is_cuda:
             return False
         wgs = text.shape[0] * ((self.out_features + 255) // 256)
         cus = torch.cuda.get_device_properties(text.device).multi_processor_count

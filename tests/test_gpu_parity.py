@@ -1832,8 +1832,8 @@ def test_wide_graph_layer_one_launch_vs_oracle(pkg, dev, precision, B, T, K, F, 
 
 def test_ace_length_graphs_take_the_eight_wavefront_layer(pkg, dev):
     """Graphs of 193..256 nodes (ACE cased, ORI_ML = 231: constant.py:267) go through the one-launch layer on their own --
-    no fused_max_t set -- and so do graphs of 161..192 nodes in batches that fill whole rounds of workgroups; graphs that would
-    leave the 256-row slot mostly empty keep linear + aggregate.
+    no fused_max_t set -- and so do graphs of 129..192 nodes (f16mx8; bf16x3: 161..192) in batches that fill whole rounds of
+    workgroups; small batches of such graphs keep linear + aggregate.
     Both paths give the oracle's numbers; a row with more neighbours than an edge list holds (16) walks its mask words."""
     from ed_gated_gcn_amd import synth
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -1853,8 +1853,27 @@ def test_ace_length_graphs_take_the_eight_wavefront_layer(pkg, dev):
         adj, csr = csr_of(B, T)
         took[(B, T)] = m.takes_fused_path(torch.empty(B, T, H, device=dev), csr)
     assert took[(2 * cus, 231)] and took[(8, 231)] and took[(8, 193)] and took[(8, 100)]
-    assert took[(2 * cus, 176)]                      # 161..192 nodes: whole rounds of workgroups only
-    assert not took[(8, 192)] and not took[(2 * cus - cus // 2, 176)] and not took[(2 * cus, 160)] and not took[(8, 129)]
+    assert took[(2 * cus, 176)] and took[(2 * cus, 160)]     # 129..192 nodes: whole rounds of workgroups only
+    assert not took[(8, 192)] and not took[(2 * cus - cus // 2, 176)] and not took[(8, 129)]
+    m.precision = "bf16x3"                               # (its main loop has no compiled-in block count: 161 and up)
+    adj, csr = csr_of(2 * cus, 160)
+    assert not m.takes_fused_path(torch.empty(2 * cus, 160, H, device=dev), csr)
+    m.precision = "f16mx8"
+    # 129-, 144-, 160-node graphs in a batch of two rounds: the second row group's main loop is compiled for 1 block
+    for T in (129, 144, 160, 200):
+        B = 2 * cus
+        adj, csr = csr_of(B, T)
+        rng = np.random.default_rng(T)
+        x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32))
+        g = torch.from_numpy(rng.uniform(-1.0, 1.0, (B, H)).astype(np.float32))
+        assert m.takes_fused_path(x.to(dev), csr)
+        with torch.no_grad():
+            out, pa, _ = m.forward_gated(x.to(dev), csr, store_gate=g.to(dev), pool_gate_a=g.to(dev), want_pool_a=True)
+        sl = slice(B - 3, B)
+        ref = ref_dense.graph_convolution(x[sl], torch.from_numpy(adj[sl].astype(np.float32)), torch.from_numpy(w), torch.from_numpy(b))
+        scale = max(1.0, float(ref.abs().max()))
+        np.testing.assert_allclose(out[sl].cpu().numpy(), (ref * g[sl, None, :]).numpy(), rtol=0, atol=TOL["f16mx8"] * scale)
+        np.testing.assert_allclose(pa[sl].cpu().numpy(), (ref * g[sl, None, :]).max(dim=1)[0].numpy(), rtol=0, atol=TOL["f16mx8"] * scale)
     # dense rows (> 16 neighbours: the mask-word walk) in a small batch
     adj, csr = csr_of(6, 231, degree=24.0)
     rng = np.random.default_rng(7)
