@@ -49,7 +49,7 @@ PROTOTYPES = {
                                         c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ggcn_gate_pool_backward_drop": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32,
                                              c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_uint64, c_i32, c_i32, c_i32, c_vp]),
-    "ggcn_layer_fused_drop": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+    "ggcn_layer_fused_drop": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_vp, c_vp, c_i32, ctypes.c_float, ctypes.c_uint64, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_dropout_mask": (c_i32, [c_i64, c_i32, ctypes.c_float, ctypes.c_uint64, c_i32, c_vp, c_vp]),
     "ggcn_colsum_workspace_bytes": (c_sz, [c_i32]),

@@ -152,7 +152,7 @@ class GatedGCNEventDetector(nn.Module):
             xg, out, _ = self.gc2.forward_gated(gcn1, csr, want_pool_a=True)           # :748-749
             xy = 0.0
         elif dropping and self.gc1.takes_dropout_path(x, csr) and self.gc2.takes_dropout_path(x, csr):
-            # ---- training with dropout, graphs of <= 32 nodes: the reference drops entries of the REPEATED [B,T,H] gates
+            # ---- training with dropout on the one-launch path (graphs of <= 256 nodes): the reference drops entries of the REPEATED [B,T,H] gates
             # (:621-625), one draw per token and feature.  The layers draw those keep factors in their own epilogues from a
             # counter-based hash of (seed, element) -- stream 1 for gate1, stream 2 for gate2 in BOTH layers, as the
             # reference's one dropped copy of gate2 serves :631 and :639 -- and again in the backward pass: nothing of
@@ -168,7 +168,7 @@ class GatedGCNEventDetector(nn.Module):
             if pooled is not None and not v54:
                 self.dropout(pooled)                                                   # :641 (unused; keeps the RNG stream)
         elif dropping:
-            # ---- longer graphs (or a layer off the one-launch path): gating, dropout and the pools as the reference's own
+            # ---- a layer off the one-launch path (weighted adjacency, > 256 nodes, ...): gating, dropout and the pools as the reference's own
             # ops around the two HIP layers (three [B,T,H] temporaries) ----
             gate1 = self.dropout(self.gate1(aspect)[:, None, :].expand(-1, T, -1))     # :621-624 (repeat, then dropout)
             gate2 = self.dropout(self.gate2(aspect)[:, None, :].expand(-1, T, -1))

@@ -205,7 +205,7 @@ int ggcn_gate_pool_backward_drop(const float *out, int64_t ldo, const float *sto
                               d_ga, d_gb, d_bsum, as_stream(stream), &d);
 }
 
-int ggcn_layer_fused_drop(const float *X, int64_t ldx, const void *wpack, const void *graph_ops,
+int ggcn_layer_fused_drop(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops,
                           const float *bias, int B, int T, int K, int F, const float *store_gate,
                           const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
                           float *pool_a, float *pool_b, int precision, float p, uint64_t seed, int sel_store,
@@ -214,7 +214,7 @@ int ggcn_layer_fused_drop(const float *X, int64_t ldx, const void *wpack, const 
     if (!(p >= 0.0f && p < 1.0f) || sel_store < 0 || sel_store > 2 || sel_a < 0 || sel_a > 2 || sel_b < 0 || sel_b > 2)
         return fail(GGCN_EINVAL, "ggcn_layer_fused_drop: p=%g streams %d %d %d", (double)p, sel_store, sel_a, sel_b);
     const DropSpec d = make_drop_spec(p, seed, sel_store, sel_a, sel_b);
-    return layer_fused(X, ldx, wpack, nullptr, graph_ops, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out,
+    return layer_fused(X, ldx, wpack, rowmask, graph_ops, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out,
                        ldo, pool_a, pool_b, nullptr, nullptr, nullptr, precision, as_stream(stream), &d);
 }
 

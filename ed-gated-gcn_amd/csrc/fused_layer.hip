@@ -276,8 +276,8 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
     const bool kfull = (a.K % BK == 0);
     a.k_steps = round_up(a.K, BK) / KSTEP;
     a.n_wg = (a.F + BN - 1) / BN;
-    if (a.drop.thr != 0 && (a.T > 32 || a.n_parts != 1 || precision == GGCN_PREC_F16MX6))
-        return fail(GGCN_EUNSUPPORTED, "%s: gate dropout is built into the one-launch layer of graphs of <= 32 nodes (bf16x3 / f16mx8)", who);
+    if (a.drop.thr != 0 && (a.n_parts != 1 || precision == GGCN_PREC_F16MX6))
+        return fail(GGCN_EUNSUPPORTED, "%s: gate dropout is built into the one-launch LAYER (bf16x3 / f16mx8), not the two-layer block", who);
     if ((int64_t)a.B * a.T * a.F >= ((int64_t)1 << 32) && a.drop.thr != 0)
         return fail(GGCN_EUNSUPPORTED, "%s: gate dropout indexes elements with 32 bits (B*T*F = %lld)", who, (long long)a.B * a.T * a.F);
     if (a.T > 32 && precision == GGCN_PREC_F16MX6)

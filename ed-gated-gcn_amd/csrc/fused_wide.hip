@@ -19,7 +19,10 @@ namespace {
 // meanwhile -- 256 registers of planes in the epilogue, so it is built for one wavefront per SIMD and the main loop runs
 // at its lone-wavefront speed: measured 4-18 % SLOWER than linear + aggregate at T = 231 (tools/wide_timing.py).  The
 // launcher takes layer_fused_wide8_kernel (below: eight wavefronts, both halves in flight) for these graphs.
-template <int SCH, bool AVEC, bool KFULL, bool VST, int SB>
+// DROP (training, bert_amir5.py:621-625): the three gates are dropped per (token, feature) -- keep factors from the
+// counter-based hash of dropout_hash.h, the same ones ggcn_gate_pool_backward_drop and ggcn_dropout_mask draw -- and the
+// pools maximise the gated, kept values themselves (every element has its own factor: no max / min shortcut).
+template <int SCH, bool AVEC, bool KFULL, bool VST, int SB, bool DROP = false>
 __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_fused_wide_kernel(const FusedArgs a)
 {
     static_assert(SB == 2 || SB == 4 || SB == 8, "a graph slot is 64, 128 or 256 rows");
@@ -138,9 +141,9 @@ __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_f
 #pragma unroll
                 for (int io = 0; io < SB; ++io) load_masks(io, mw[io]);
             }
-            float vmax[RN], vmin[RN];
+            float vmax[RN], vmin[RN], pmax_a[RN], pmax_b[RN];
 #pragma unroll
-            for (int j = 0; j < RN; ++j) { vmax[j] = -INFINITY; vmin[j] = INFINITY; }
+            for (int j = 0; j < RN; ++j) { vmax[j] = -INFINITY; vmin[j] = INFINITY; pmax_a[j] = -INFINITY; pmax_b[j] = -INFINITY; }
 #pragma unroll
             for (int io = 0; io < SB; ++io) {
                 const int node0 = 32 * io;
@@ -178,15 +181,28 @@ __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_f
                     float *tile = decltype(has_out)::value ? out + ((int64_t)g * T + node0) * ldo + (nt0 + j) * NT : nullptr;
                     const float sg = store_gate ? vsg[s][j] : 1.0f;
                     const float bj = bias ? vb[j] : 0.0f;
+                    const float gaj = pool_gate_a ? vga[s][j] : 1.0f, gbj = pool_gate_b ? vgb[s][j] : 1.0f;
+                    const uint32_t didx0 = DROP ? (uint32_t)(((int64_t)g * T + node0 + 4 * h) * F + (nt0 + j) * NT + c) : 0u;   // element of row 4h of the block
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
                         const float v = y[r] * rinv[r] + bj;      // gcn.py:41,43
-                        if (vst) stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = v * sg;
+                        float vs = v * sg;
+                        if constexpr (DROP) {
+                            const uint32_t hh = drop_hash(didx0 + (uint32_t)(row0 * F), a.drop.seed_lo, a.drop.seed_hi);
+                            vs *= drop_keep(hh, a.drop.sel[0], a.drop.thr, a.drop.scale);
+                            if (node0 + row0 + 4 * h < T) {
+                                pmax_a[j] = fmaxf(pmax_a[j], v * gaj * drop_keep(hh, a.drop.sel[1], a.drop.thr, a.drop.scale));
+                                pmax_b[j] = fmaxf(pmax_b[j], v * gbj * drop_keep(hh, a.drop.sel[2], a.drop.thr, a.drop.scale));
+                            }
+                        }
+                        if (vst) stage_lds[(row0 + 4 * h) * 64 + ((32 * j + c) ^ (32 * h))] = vs;
                         if (node0 + row0 + 4 * h < T) {
-                            if (direct_store && col_ok[j]) tile[lane_off + row0 * ldo] = v * sg;
-                            vmax[j] = fmaxf(vmax[j], v);
-                            vmin[j] = fminf(vmin[j], v);
+                            if (direct_store && col_ok[j]) tile[lane_off + row0 * ldo] = vs;
+                            if constexpr (!DROP) {
+                                vmax[j] = fmaxf(vmax[j], v);
+                                vmin[j] = fminf(vmin[j], v);
+                            }
                         }
                     }
                 }
@@ -211,12 +227,19 @@ __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_f
 #pragma unroll
             for (int j = 0; j < RN; ++j) {
                 if (nt0 + j >= n_tiles_total) break;
-                const float mx = fmaxf(vmax[j], upper_half_to_lower(vmax[j]));
-                const float mn = fminf(vmin[j], upper_half_to_lower(vmin[j]));
+                float pa, pb;
+                if constexpr (DROP) {
+                    pa = fmaxf(pmax_a[j], upper_half_to_lower(pmax_a[j]));
+                    pb = fmaxf(pmax_b[j], upper_half_to_lower(pmax_b[j]));
+                } else {
+                    const float mx = fmaxf(vmax[j], upper_half_to_lower(vmax[j]));
+                    const float mn = fminf(vmin[j], upper_half_to_lower(vmin[j]));
+                    const float ga = pool_gate_a ? vga[s][j] : 1.0f, gb = pool_gate_b ? vgb[s][j] : 1.0f;
+                    pa = ga * (ga >= 0.0f ? mx : mn);
+                    pb = gb * (gb >= 0.0f ? mx : mn);
+                }
                 if (h == 0 && col_ok[j]) {
                     const int gn = (nt0 + j) * NT + c;
-                    const float ga = pool_gate_a ? vga[s][j] : 1.0f, gb = pool_gate_b ? vgb[s][j] : 1.0f;
-                    const float pa = ga * (ga >= 0.0f ? mx : mn), pb = gb * (gb >= 0.0f ? mx : mn);
                     if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
                     if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
                     dot = fmaf(pa, pb, dot);
@@ -238,13 +261,18 @@ __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_f
 
 int launch_fused_wide(const char *who, const FusedArgs &a, int precision, int sb, bool fast, bool vst, int64_t gridw, hipStream_t st)
 {
-#define GGCN_LAUNCHW(SC, AV, KF, VS, SBV) \
-    hipLaunchKernelGGL((layer_fused_wide_kernel<SC, AV, KF, VS, SBV>), dim3((unsigned)gridw), dim3(kThreads), 0, st, a)
-#define GGCN_PICKW(SC, SBV)                                              \
-    do {                                                                 \
-        if (fast && vst) GGCN_LAUNCHW(SC, true, true, true, SBV);        \
-        else if (fast) GGCN_LAUNCHW(SC, true, true, false, SBV);         \
-        else GGCN_LAUNCHW(SC, false, false, false, SBV);                 \
+#define GGCN_LAUNCHW(SC, AV, KF, VS, SBV, DR) \
+    hipLaunchKernelGGL((layer_fused_wide_kernel<SC, AV, KF, VS, SBV, DR>), dim3((unsigned)gridw), dim3(kThreads), 0, st, a)
+#define GGCN_PICKWD(SC, SBV, DR)                                             \
+    do {                                                                     \
+        if (fast && vst) GGCN_LAUNCHW(SC, true, true, true, SBV, DR);        \
+        else if (fast) GGCN_LAUNCHW(SC, true, true, false, SBV, DR);         \
+        else GGCN_LAUNCHW(SC, false, false, false, SBV, DR);                 \
+    } while (0)
+#define GGCN_PICKW(SC, SBV)                                                  \
+    do {                                                                     \
+        if (a.drop.thr != 0) GGCN_PICKWD(SC, SBV, true);                     \
+        else GGCN_PICKWD(SC, SBV, false);                                    \
     } while (0)
 #if GGCN_LAB_WIDE_SB8
     if (sb == 8) { if (precision == GGCN_PREC_F16MX8) GGCN_PICKW(1, 8); else GGCN_PICKW(0, 8); return check_launch(who); }
@@ -253,6 +281,7 @@ int launch_fused_wide(const char *who, const FusedArgs &a, int precision, int sb
     if (precision == GGCN_PREC_F16MX8) { if (sb == 2) GGCN_PICKW(1, 2); else GGCN_PICKW(1, 4); }
     else { if (sb == 2) GGCN_PICKW(0, 2); else GGCN_PICKW(0, 4); }
 #undef GGCN_PICKW
+#undef GGCN_PICKWD
 #undef GGCN_LAUNCHW
     return check_launch(who);
 }

@@ -29,9 +29,12 @@ constexpr int kW8Stage = 4096;                // per wavefront: 32 rows x 32 col
 constexpr int kW8Lds = kW8Ex + 8 * kW8Stage;  // 160 KiB
 static_assert(2 * kLdsBytes <= kW8Ex && kW8Lds <= 160 * 1024, "the stage buffers of both row groups lie under the exchange area");
 
-template <int SCH, bool AVEC, bool KFULL, bool VST>
+// DROP (training, bert_amir5.py:621-625): per-(token, feature) keep factors of the three gates (dropout_hash.h), the pools
+// maximise the gated, kept values (edge-list epilogue only).
+template <int SCH, bool AVEC, bool KFULL, bool VST, bool DROP = false>
 __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const FusedArgs a)
 {
+    static_assert(!(DROP && GGCN_LAB_WIDE8_DENSE), "gate dropout lives in the edge-list epilogue");
     extern __shared__ __attribute__((aligned(16))) char lds8[];
     const int B = a.B, T = a.T, K = a.K, F = a.F;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -354,10 +357,10 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
 #pragma unroll
     for (int j = 0; j < RN; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { vmax[j][k] = -INFINITY; vmin[j][k] = INFINITY; }
+        for (int k = 0; k < 4; ++k) { vmax[j][k] = -INFINITY; vmin[j][k] = DROP ? -INFINITY : INFINITY; }
     // bias and store gate of this lane's columns for both column tiles: asked for here, used behind two barriers
     const float *dummy = a.X;
-    float b4[RN][4], sg4[RN][4];
+    float b4[RN][4], sg4[RN][4], ga4[RN][4], gb4[RN][4];   // (the pool gates per lane column: DROP only)
     bool cok[RN][4];
 #pragma unroll
     for (int j = 0; j < RN; ++j)
@@ -368,6 +371,10 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
             const int cc = cok[j][k] ? col : 0;
             b4[j][k] = bias ? (bias ? bias : dummy)[cc] : 0.0f;
             sg4[j][k] = store_gate ? (store_gate ? store_gate : dummy)[(int64_t)g * F + cc] : 1.0f;
+            if constexpr (DROP) {
+                ga4[j][k] = pool_gate_a ? (pool_gate_a ? pool_gate_a : dummy)[(int64_t)g * F + cc] : 1.0f;
+                gb4[j][k] = pool_gate_b ? (pool_gate_b ? pool_gate_b : dummy)[(int64_t)g * F + cc] : 1.0f;
+            }
         }
     const int tile_lane = cg * (256 * 128) + 16 * cl, zero_lane = zero_off + 16 * cl;
     const int n_steps = ((GGCN_LAB_OFF) & 16) ? 1 : 16;   // (timing build: one row step only)
@@ -439,8 +446,15 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                 for (int k = 0; k < 4; ++k) {
                     const float v = s4[k] * inv + b4[j][k];                 // gcn.py:41,43
                     o4[k] = v * sg4[j][k];
-                    vmax[j][k] = vmaxf_raw(vmax[j][k], v);
-                    vmin[j][k] = vminf_raw(vmin[j][k], v);
+                    if constexpr (DROP) {   // vmax / vmin carry the two pools' running maxima of the gated, kept values
+                        const uint32_t hh = drop_hash((uint32_t)(((int64_t)g * T + row) * F + col0 + k), a.drop.seed_lo, a.drop.seed_hi);
+                        o4[k] *= drop_keep(hh, a.drop.sel[0], a.drop.thr, a.drop.scale);
+                        vmax[j][k] = vmaxf_raw(vmax[j][k], v * ga4[j][k] * drop_keep(hh, a.drop.sel[1], a.drop.thr, a.drop.scale));
+                        vmin[j][k] = vmaxf_raw(vmin[j][k], v * gb4[j][k] * drop_keep(hh, a.drop.sel[2], a.drop.thr, a.drop.scale));
+                    } else {
+                        vmax[j][k] = vmaxf_raw(vmax[j][k], v);
+                        vmin[j][k] = vminf_raw(vmin[j][k], v);
+                    }
                 }
                 if (out && !((GGCN_LAB_OFF) & 8)) {   // (timing build: no stores)
                     float *dst = out + ((int64_t)g * T + row) * ldo + col0;
@@ -465,7 +479,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
 #pragma unroll
                 for (int d = 8; d <= 32; d <<= 1) {
                     vmax[j][k] = vmaxf_raw(vmax[j][k], __shfl_xor(vmax[j][k], d));
-                    vmin[j][k] = vminf_raw(vmin[j][k], __shfl_xor(vmin[j][k], d));
+                    vmin[j][k] = DROP ? vmaxf_raw(vmin[j][k], __shfl_xor(vmin[j][k], d)) : vminf_raw(vmin[j][k], __shfl_xor(vmin[j][k], d));
                 }
         float *pl = reinterpret_cast<float *>(lds8 + kW8Ex);   // [wavefront][max / min][column tile][32]
         __syncthreads();
@@ -487,10 +501,11 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                     const int gn = (nt0 + j) * NT + lane;
                     if (nt0 + j < n_tiles_total && gn < F) {
                         const float mx = fmaxf(pl[((wave * 2 + 0) * RN + j) * 32 + lane], pl[(((wave + 4) * 2 + 0) * RN + j) * 32 + lane]);
-                        const float mn = fminf(pl[((wave * 2 + 1) * RN + j) * 32 + lane], pl[(((wave + 4) * 2 + 1) * RN + j) * 32 + lane]);
+                        const float m1 = pl[((wave * 2 + 1) * RN + j) * 32 + lane], m2 = pl[(((wave + 4) * 2 + 1) * RN + j) * 32 + lane];
+                        const float mn = DROP ? fmaxf(m1, m2) : fminf(m1, m2);
                         const float ga = pool_gate_a ? pool_gate_a[(int64_t)g * F + gn] : 1.0f;
                         const float gb = pool_gate_b ? pool_gate_b[(int64_t)g * F + gn] : 1.0f;
-                        const float pa = ga * (ga >= 0.0f ? mx : mn), pb = gb * (gb >= 0.0f ? mx : mn);
+                        const float pa = DROP ? mx : ga * (ga >= 0.0f ? mx : mn), pb = DROP ? mn : gb * (gb >= 0.0f ? mx : mn);
                         if (pool_a) pool_a[(int64_t)g * F + gn] = pa;
                         if (pool_b) pool_b[(int64_t)g * F + gn] = pb;
                         dot = fmaf(pa, pb, dot);
@@ -512,13 +527,18 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
 
 int launch_fused_wide8(const char *who, const FusedArgs &a, int precision, bool fast, bool vst, int64_t gridw, hipStream_t st)
 {
-#define GGCN_LAUNCH8(SC, AV, KF, VS)                                                                                      \
+#define GGCN_LAUNCH8D(SC, AV, KF, VS, DR)                                                                                 \
     do {                                                                                                                  \
-        auto kern = layer_fused_wide8_kernel<SC, AV, KF, VS>;                                                             \
+        auto kern = layer_fused_wide8_kernel<SC, AV, KF, VS, DR>;                                                           \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                 kW8Lds) != hipSuccess)                                                                    \
             return fail(GGCN_ELAUNCH, "%s: cannot reserve %d bytes of LDS", who, kW8Lds);                                 \
         hipLaunchKernelGGL(kern, dim3((unsigned)gridw), dim3(kW8Threads), kW8Lds, st, a);                                 \
+    } while (0)
+#define GGCN_LAUNCH8(SC, AV, KF, VS)                                            \
+    do {                                                                        \
+        if (a.drop.thr != 0 && !GGCN_LAB_WIDE8_DENSE) GGCN_LAUNCH8D(SC, AV, KF, VS, !GGCN_LAB_WIDE8_DENSE); \
+        else GGCN_LAUNCH8D(SC, AV, KF, VS, false);                              \
     } while (0)
 #define GGCN_PICK8(SC)                                      \
     do {                                                    \
@@ -530,6 +550,7 @@ int launch_fused_wide8(const char *who, const FusedArgs &a, int precision, bool 
     else GGCN_PICK8(0);
 #undef GGCN_PICK8
 #undef GGCN_LAUNCH8
+#undef GGCN_LAUNCH8D
     return check_launch(who);
 }
 

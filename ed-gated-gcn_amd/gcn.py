@@ -341,8 +341,8 @@ class GraphConvolution(nn.Module):
 
     def takes_dropout_path(self, text, csr):
         """True when the gates' training-mode dropout (``bert_amir5.py:621-625``) can be drawn inside the layer launch:
-        the one-launch layer for graphs of <= 32 nodes."""
-        return self.takes_fused_path(text, csr) and csr.T <= 32 and text.shape[0] * text.shape[1] * self.out_features < 2 ** 32
+        every one-launch form (graphs of <= 256 nodes on the fused path), element index below 2^32."""
+        return self.takes_fused_path(text, csr) and text.shape[0] * text.shape[1] * self.out_features < 2 ** 32
 
     def forward_gated(self, text, adj, store_gate=None, pool_gate_a=None, pool_gate_b=None,
                       want_out=True, want_pool_a=False, want_pool_b=False, _internal=False,
@@ -378,7 +378,7 @@ class GraphConvolution(nn.Module):
         this launch reduce the partials an earlier launch wrote into the scalar ``xy``
         (``bert_amir5.py:638`` without its own launches).
 
-        ``dropout=(p, seed, (stream_store, stream_a, stream_b))`` (one-launch path, graphs of <= 32 nodes): the three gates
+        ``dropout=(p, seed, (stream_store, stream_a, stream_b))`` (one-launch path: ``takes_dropout_path``): the three gates
         are dropped per (token, feature) like the reference's repeated ``[B,T,H]`` gates (``bert_amir5.py:621-625``);
         stream 0 = not dropped, 1 / 2 = the two independent Bernoulli streams of ``seed`` (``include/ggcn.h``)."""
         self._check(text)
@@ -393,7 +393,7 @@ class GraphConvolution(nn.Module):
             if text.dtype != torch.float32:
                 raise RuntimeError("training through the HIP layer needs float32 features")
             if dropout is not None and not self.takes_dropout_path(text, csr):
-                raise RuntimeError("dropout= needs the one-launch layer of graphs of <= 32 nodes (takes_dropout_path)")
+                raise RuntimeError("dropout= needs the one-launch layer (takes_dropout_path: takes_fused_path and B*T*F < 2^32)")
             out, pa, pb = _GatedLayerFunction.apply(text, self.weight, self.bias, store_gate, pool_gate_a,
                                                     pool_gate_b, self, csr, want_pool_a, want_pool_b, dropout)
             return (out if want_out else None), pa, pb
@@ -413,7 +413,7 @@ class GraphConvolution(nn.Module):
         half = text.dtype == torch.float16
         use_fused = self.takes_fused_path(text, csr)
         if dropout is not None and not (use_fused and self.takes_dropout_path(text, csr)):
-            raise RuntimeError("dropout= needs the one-launch layer of graphs of <= 32 nodes (takes_dropout_path)")
+            raise RuntimeError("dropout= needs the one-launch layer (takes_dropout_path: takes_fused_path and B*T*F < 2^32)")
         if (overlap_partial is not None or overlap_reduce is not None) and not use_fused:
             raise RuntimeError("overlap_partial / overlap_reduce need the one-launch layer (takes_fused_path)")
         use_long = ((not use_fused) and self.takes_long_path(text, csr) and x2d.data_ptr() % 16 == 0
@@ -429,7 +429,7 @@ class GraphConvolution(nn.Module):
                 kprec = "f16mx8" if self.precision == "f16mx6" else self.precision   # the fp6 kernel has no dropout epilogue
                 pack = self._packed_weight(lib, st, precision=kprec)
                 dp, dseed, (ss, sa, sb) = dropout
-                _capi.check(lib.ggcn_layer_fused_drop(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack), _capi.ptr(csr.graph_ops),
+                _capi.check(lib.ggcn_layer_fused_drop(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack), _capi.ptr(csr.rowmask), _capi.ptr(csr.graph_ops),
                                                       _capi.ptr(bias), B, T, self.in_features, F, _capi.ptr(store_gate),
                                                       _capi.ptr(pool_gate_a), _capi.ptr(pool_gate_b), _capi.ptr(out), F,
                                                       _capi.ptr(pa), _capi.ptr(pb), _capi.PREC[kprec], float(dp), int(dseed),

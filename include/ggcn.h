@@ -295,7 +295,7 @@ int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void
                      float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
                      float *x1, float *y1, float *pool_out, float *overlap_partial,
                      int precision, ggcn_stream_t stream);
-/* ---- training-mode dropout of the gates inside the one-launch layer (graphs of <= 32 nodes) ------------------
+/* ---- training-mode dropout of the gates inside the one-launch layer (graphs of <= 256 nodes) ------------------
  * models/bert_amir5.py:621-625 repeats each gate to [B,T,H] and THEN applies F.dropout: one Bernoulli draw per (token,
  * feature) and gate.  Here the keep factors k[t,f] in {0, 1/(1-p)} come from a counter-based hash of (seed, element)
  * (csrc/dropout_hash.h) evaluated in the layer's epilogue -- nothing of size [B,T,H] is materialised -- and again in
@@ -303,9 +303,10 @@ int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void
  * not dropped).  The block uses stream 1 for gate1 and stream 2 for gate2 in BOTH layers (the reference drops gate2
  * once and uses it at :631 and :639):  layer 1: (store 0, pool a 1, pool b 2);  layer 2: (store 2, pool a 2, pool b 0).
  *   out = y * store_gate * k_store,   pool_x = max_t (y * pool_gate_x * k_x)
- * precision GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8; B*T*F < 2^32.  ggcn_dropout_mask writes k (rows x F floats) of one
- * stream: what a test or a host-side oracle multiplies the repeated gate by. */
-int ggcn_layer_fused_drop(const float *X, int64_t ldx, const void *wpack, const void *graph_ops,
+ * precision GGCN_PREC_BF16X3 or GGCN_PREC_F16MX8; B*T*F < 2^32; rowmask / graph_ops as in ggcn_layer_fused (T <= 32 reads
+ * graph_ops, larger graphs the row masks).  ggcn_dropout_mask writes k (rows x F floats) of one stream: what a test or a
+ * host-side oracle multiplies the repeated gate by. */
+int ggcn_layer_fused_drop(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops,
                           const float *bias, int B, int T, int K, int F,
                           const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
                           float *out, int64_t ldo, float *pool_a, float *pool_b, int precision,

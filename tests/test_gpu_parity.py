@@ -1698,14 +1698,17 @@ def test_gate_dropout_masks_are_bernoulli_independent_and_reproducible(pkg, dev)
     assert torch.equal(_drop_mask(pkg, dev, 64, 32, 0.5, 7, 0), torch.ones(64, 32, device=dev))
 
 
+@pytest.mark.parametrize("T", [31, 60, 100, 200], ids=["T31", "T60-64row", "T100-128row", "T200-eight-wavefronts"])
 @pytest.mark.parametrize("precision", ["bf16x3", "f16mx8", "f16mx6"])
-def test_block_layers_with_gate_dropout_vs_oracle_on_the_exported_masks(pkg, dev, precision):
+def test_block_layers_with_gate_dropout_vs_oracle_on_the_exported_masks(pkg, dev, precision, T):
     """bert_amir5.py:621-640 in training mode: gates repeated to [B,T,H], dropped per token (:621-625), then :626-640.
     The two layer launches draw the keep factors themselves (stream 1 = gate1, stream 2 = gate2 in both layers); the oracle
     gets the same factors from ggcn_dropout_mask and evaluates the reference's formulas -- forward and, through torch
     autograd, backward."""
     from ed_gated_gcn_amd import synth
-    B, T, H, p, seed = 12, 31, 128, 0.5, 2 ** 40 + 99
+    if precision == "f16mx6" and T > 32:
+        pytest.skip("the fp6 experiment takes graphs of <= 32 nodes")
+    B, H, p, seed = 12, 128, 0.5, 2 ** 40 + 99
     rng = np.random.default_rng(5)
     adj = synth.dependency_batch(B, T, 3.5, seed=8, lengths=rng.integers(4, T + 1, size=B))
     t = torch.from_numpy
