@@ -70,9 +70,21 @@ class GatedGCNEventDetector(nn.Module):
         # no precision asked for (opt.ggcn_precision / GGCN_PRECISION): inference picks the faster "f16mx8" whenever the
         # weights PROVE its fp16 range sufficient for this model (_proved_precision), "bf16x3" otherwise
         self._auto_precision = getattr(opt, "ggcn_precision", None) is None and "GGCN_PRECISION" not in os.environ
+        self._assigned = (self.gc1.precision, self.gc2.precision)   # what _assign / the constructor last put there (_auto)
         self._proved = None
 
     F16_RANGE_MARGIN = 32752.0   # half of fp16's largest finite value
+
+    def _auto(self):
+        """Still choosing the layers' precision ourselves?  A precision assigned to gc1 / gc2 after construction
+        (``model.gc1.precision = "fp32"``) is the user's explicit choice from then on, like opt.ggcn_precision."""
+        if self._auto_precision and (self.gc1.precision, self.gc2.precision) != self._assigned:
+            self._auto_precision = False
+        return self._auto_precision
+
+    def _assign(self, precision):
+        self.gc1.precision = self.gc2.precision = precision
+        self._assigned = (precision, precision)
 
     def _proved_precision(self, csr):
         """"f16mx8" when every value that kernel rounds to fp16 is bounded below ``F16_RANGE_MARGIN`` by the weights alone,
@@ -125,10 +137,10 @@ class GatedGCNEventDetector(nn.Module):
         v54, nogate = self.VARIANT == "54", self.VARIANT == "55nogate"
         if not grad and not dropping:
             # ---- inference: everything from `aspect` to `scores` on the HIP path, gates kept [B,H] ----
-            if self._auto_precision:
+            if self._auto():
                 if isinstance(adj, torch.Tensor):
                     adj = self.gc1._as_csr(adj, x)   # (the block would convert it anyway; identity-cached)
-                self.gc1.precision = self.gc2.precision = self._proved_precision(adj)
+                self._assign(self._proved_precision(adj))
             if nogate:   # :736-752: gc2(gc1(x)) and its max-pool -- the block with unit gates (one launch for T <= 32)
                 ones = x.new_ones(B, 2 * self.hidden_dim)
                 r = gated_gcn_block(x, adj, ones, ones, self.gc1, self.gc2)
@@ -144,8 +156,8 @@ class GatedGCNEventDetector(nn.Module):
                 logits = self.dense(torch.cat([anchor_rep, aspect, r["out"]], dim=1))     # :642-643 (dropout = identity)
                 scores, kl = scores_and_kl(r["x"], aspect, logits, self.fc[0], dist)      # :645-648, one launch
             return logits, xy, kl, scores
-        if self._auto_precision:
-            self.gc1.precision = self.gc2.precision = "bf16x3"   # training: the full-range default
+        if self._auto():
+            self._assign("bf16x3")   # training: the full-range default
         csr = adj if not isinstance(adj, torch.Tensor) else self.gc1._as_csr(adj, x)
         if nogate:
             gcn1 = self.gc1(x, csr)                                                    # :736

@@ -47,7 +47,10 @@ def _block_operands(gc1, gc2, lib, st, precision=None):
     prec = _capi.PREC[precision]
     key = (w1.data_ptr(), tensor_version(w1), w2.data_ptr(), tensor_version(w2), None if b1 is None else (b1.data_ptr(), tensor_version(b1)),
            w1.device, prec)
-    cached = getattr(gc2, "_block_ops", None)
+    store = getattr(gc2, "_block_ops", None)
+    if not isinstance(store, dict):
+        store = gc2._block_ops = {}   # one entry per precision (like _packed_weight): an eval / train switch of the classifier folds nothing again
+    cached = store.get(prec)
     if cached is None or cached[0] != key:
         K, F1, F2 = gc1.in_features, gc1.out_features, gc2.out_features
         dev = w1.device
@@ -63,7 +66,7 @@ def _block_operands(gc1, gc2, lib, st, precision=None):
         pack12 = torch.empty(lib.ggcn_weight_pack_bytes(K, F2, prec), dtype=torch.uint8, device=dev)
         _capi.check(lib.ggcn_weight_pack(_capi.ptr(w12), F2, K, F2, prec, 0, _capi.ptr(pack12), st), "ggcn_weight_pack(W12)")
         cached = (key, pack12, mid)
-        gc2._block_ops = cached
+        store[prec] = cached
     return gc1._packed_weight(lib, st, precision=precision), cached[1], cached[2]
 
 

@@ -581,6 +581,18 @@ def test_config5_classifier_golden_reference_logits(pkg, dev, golden_dir):
     with torch.no_grad():
         m2(inputs)
     assert not m2._auto_precision and m2.gc1.precision == "bf16x3"
+    # ... and neither is a precision assigned to the layers after construction: it ends the automatic choice
+    m3 = pkg.GatedGCNEventDetector(EncoderStandIn(int(g["seed_encoder"])), types.SimpleNamespace(
+        device=dev, dropout=0.25, polarities_dim=int(g["n_class"]))).to(dev).eval()
+    with torch.no_grad():
+        m3(inputs)
+    assert m3._auto_precision and m3.gc1.precision in ("f16mx8", "bf16x3")
+    m3.gc1.precision = m3.gc2.precision = "fp32"
+    with torch.no_grad():
+        m3(inputs)
+        m3.train(); m3(inputs); m3.eval()
+    assert not m3._auto_precision and m3.gc1.precision == m3.gc2.precision == "fp32"
+    assert isinstance(model.gc2._block_ops, dict) and len(model.gc2._block_ops) == 2   # one folded W12 per precision (f16mx8, then bf16x3), kept across switches
 
 
 @pytest.mark.parametrize("cls_name,oracle_name,fixture", [("GatedGCNEventDetector54", "BertAmir54Oracle", "amir54_full.npz"),
