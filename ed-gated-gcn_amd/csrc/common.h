@@ -91,6 +91,10 @@ int colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *works
 
 size_t dweight_workspace_bytes(int64_t N, int K, int F);
 size_t dweight_bx3_workspace_bytes(int64_t N, int K, int F);
+bool dweight_tn_takes(const float *X, int64_t ldx, const float *G, int64_t ldg, int K, int F);   // dweight_tn.hip
+size_t dweight_tn_workspace_bytes(int64_t N, int K, int F);
+int dweight_tn(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F, float *dW, int64_t lddw,
+               void *workspace, hipStream_t st);
 int dweight_bx3(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F, float *dW,
                 int64_t lddw, void *workspace, hipStream_t st);
 int weight_pack_rows(const float *W, int64_t ldw, int64_t K_valid, int F, int k_steps_total, void *pack, hipStream_t st);

@@ -15,6 +15,8 @@
 #include "bf16x3_core.h"
 #include "common.h"
 
+#include <cstdlib>
+
 namespace ggcn {
 namespace {
 
@@ -145,7 +147,8 @@ size_t dweight_bx3_workspace_bytes(int64_t N, int K, int F)
 {
     if (N <= 0 || K <= 0 || F <= 0) return 0;
     const Plan p = plan_for(N, K, F);
-    return up256(p.xt_bytes) + up256(p.pack_bytes) + up256(p.slab_bytes);
+    const size_t a = up256(p.xt_bytes) + up256(p.pack_bytes) + up256(p.slab_bytes), b = dweight_tn_workspace_bytes(N, K, F);
+    return a > b ? a : b;   // (the caller does not know yet which form its pointers will take)
 }
 
 int dweight_bx3(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F, float *dW,
@@ -155,6 +158,8 @@ int dweight_bx3(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_
     if (N <= 0 || K <= 0 || F <= 0) return fail(GGCN_EINVAL, "ggcn_dweight: N=%lld K=%d F=%d must be positive", (long long)N, K, F);
     if (ldx < K || ldg < F || lddw < F) return fail(GGCN_EINVAL, "ggcn_dweight: leading dimension too small");
     if (!aligned16(workspace)) return fail(GGCN_EINVAL, "ggcn_dweight: workspace must be 16-byte aligned");
+    // 16-byte aligned rows: the native TN form (dweight_tn.hip: both operands read as they lie, no transpose / pack pass)
+    if (dweight_tn_takes(X, ldx, G, ldg, K, F) && !getenv("GGCN_DWEIGHT_TRANSPOSE")) return dweight_tn(X, ldx, G, ldg, N, K, F, dW, lddw, workspace, st);
     const Plan p = plan_for(N, K, F);
     if (p.ksteps_total > 65535 * 16 || p.n_pad > (int64_t)INT32_MAX)
         return fail(GGCN_EUNSUPPORTED, "ggcn_dweight: too many node rows for the bf16x3 form");

@@ -1,0 +1,303 @@
+// Weight gradient dW[K,F] = X[N,K]^T . dH[N,F] (backward of models/gcn.py:34 under train.py:120) as a native "TN" product on
+// the bf16 matrix cores: the reduction runs over the NODE rows of both operands, which is the row index they are stored by,
+// so both MFMA operands are COLUMNS of a [node][feature] tile.  dweight_bx3.hip brings the product into the forward's shape
+// first (a transpose pass of X and a fragment-order pack of dH: two extra round trips of [N,768] through HBM, 40 % of its
+// 0.83 ms); here both tiles go to LDS exactly as they lie in memory and gfx950's transposing LDS read (ds_read_b64_tr_b16,
+// cdna guide T10) delivers their columns as operand fragments:
+//
+//   per stage = 16 nodes = ONE k-step of v_mfma_f32_32x32x16_bf16:
+//     X  tile [16 nodes][128 features]  fp32 -> bf16 hi + lo planes (x = hi + lo, residual 2^-17 |x|)      8 KiB
+//     dH tile [16 nodes][256 features]  likewise, as two 128-column images                                  16 KiB
+//     LDS image of a plane: 256-byte rows, 16-byte chunk ch of row r at ch ^ (((r&3)<<2) | ((r>>2)&3))  (T10 image (b):
+//     conflict-free for the 8-byte writes of the staging pass and for the transposed reads)
+//     A fragment of output rows 32 i .. 32 i + 31 (= X features): lane (r, h) holds nodes 8h .. 8h+7 of column 32 i + r;
+//     B fragment of output columns likewise from the dH image -- two ds_read_b64_tr_b16 each
+//     acc[i][j] += Ahi.Bhi + Alo.Bhi + Ahi.Blo          (bf16x3: the fp32 exponent range gradients need, ~1e-5 relative)
+//   workgroup = 4 wavefronts = a [128 x 256] tile of dW over one chunk of the node axis (split-K); wavefront = 128 x 64;
+//   double-buffered LDS (48 KiB), global loads one stage ahead in registers, one barrier per stage; two workgroups per CU.
+//   The chunks' partial tiles go to a [S][K][F] slab array and are added in a fixed order (no float atomics: bitwise
+//   reproducible), as in dweight_bx3.hip, whose plan (chunks per XCD) this kernel shares.
+// Needs 16-byte aligned rows (ldx, ldg multiples of 4); other shapes keep the transpose form.
+#include "bf16x3_core.h"
+#include "common.h"
+
+#include <cstdlib>
+
+namespace ggcn {
+namespace {
+
+using namespace bx3;
+
+constexpr int TN_NODES = 16;                 // nodes per stage
+constexpr int TN_BM = 128, TN_BN = 256;      // output tile: X features x dH features
+constexpr int kPlaneX = TN_NODES * 256;      // 4 KiB: [16][128] bf16
+constexpr int kTnBuf = 2 * kPlaneX + 4 * kPlaneX;   // X hi, lo + dH (2 images x hi, lo) = 24 KiB
+constexpr int kTnLds = 2 * kTnBuf;           // 48 KiB
+
+__device__ __forceinline__ int tn_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// 4 fp32 -> bf16 hi and lo quadruples (lo = bf16(v - hi)); vectors, so that hipcc packs pairs with v_cvt_pk_bf16_f32
+__device__ __forceinline__ void split_bf16x4(const float4 &v, bf16x4 &hi, bf16x4 &lo)
+{
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    __bf16 h[4], l[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        h[c] = (__bf16)x[c];
+        l[c] = (__bf16)(x[c] - (float)h[c]);
+    }
+    hi = bf16x4{h[0], h[1], h[2], h[3]};
+    lo = bf16x4{l[0], l[1], l[2], l[3]};
+}
+
+// One transposed read of 4 x 16-bit per lane; OFF: a compile-time byte offset (the lo plane lies kPlaneX behind the hi plane)
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read(unsigned addr)
+{
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// byte offset, inside a [16][128] plane image, of this lane's share of the transposed read that delivers nodes
+// 8h + 4 half .. + 3 of column 32 blk + (lane & 31)  (T10: lane 4q + p of a 16-lane group supplies row q, columns 4p .. 4p + 3)
+__device__ __forceinline__ int tr_lane_off(int blk, int half, int lane)
+{
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    const int h = g >> 1;
+    const int c0 = blk * 32 + 16 * (g & 1);
+    return tn_off(8 * h + 4 * half + q, (c0 >> 3) + (p >> 1)) + 8 * (p & 1);
+}
+// hi and lo fragments (8 values each) of one column block from two lane addresses (the two row halves)
+__device__ __forceinline__ void tr_fragments(unsigned a0, unsigned a1, bf16x8 &hi, bf16x8 &lo)
+{
+    union { bf16x8 v; s16x4 half[2]; } uh, ul;
+    uh.half[0] = tr_read<0>(a0); uh.half[1] = tr_read<0>(a1);
+    ul.half[0] = tr_read<kPlaneX>(a0); ul.half[1] = tr_read<kPlaneX>(a1);
+    hi = uh.v; lo = ul.v;
+}
+
+// FULLC: K % 128 == 0 and F % 256 == 0 (no column of a tile lies outside the matrices)
+template <bool FULLC>
+__global__ __launch_bounds__(kThreads, 2) void dweight_tn_kernel(const float *__restrict__ X, int64_t ldx,
+                                                                 const float *__restrict__ G, int64_t ldg, int64_t N, int K, int F,
+                                                                 float *__restrict__ slabs, int64_t chunk_rows, int n_splits,
+                                                                 int m_tiles, int n_wg)
+{
+    __shared__ __attribute__((aligned(16))) char lds[kTnLds];
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int tiles = m_tiles * n_wg;
+    const int split = xcd + 8 * (qb / tiles), tile = qb % tiles;
+    if (split >= n_splits) return;  // whole workgroup, before any barrier
+    const int m_tile = tile / n_wg, n_wgi = tile % n_wg;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = m_tile * TN_BM, n0 = n_wgi * TN_BN;
+    const int64_t row0 = (int64_t)split * chunk_rows;
+    const int64_t rows_end = row0 + chunk_rows < N ? row0 + chunk_rows : N;
+    const int stages = (int)((chunk_rows + TN_NODES - 1) / TN_NODES);
+
+    // staging: X tile = 512 pieces of 16 B (2 per thread), dH tile = 1024 pieces (4 per thread); piece idx: node = idx / (cols/4)
+    int xnode[2], xcol[2], gnode[4], gcol[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) { const int idx = tid + 256 * p; xnode[p] = idx >> 5; xcol[p] = (idx & 31) * 4; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { const int idx = tid + 256 * p; gnode[p] = idx >> 6; gcol[p] = (idx & 63) * 4; }
+    float4 rx[2], rg[4];
+    // Both operands behind buffer resources whose extent ends with the chunk's last row: a stage past the chunk (or the tail
+    // of the last chunk) reads zeros by itself, the lane offsets are fixed before the loop and the stage offset is a scalar --
+    // no 64-bit lane arithmetic, no validity test per stage.  (The launcher keeps a chunk's rows below 2 GiB.)
+    constexpr int kRsrcFlags = 0x00020000;   // raw buffer, 32-bit elements (gfx9 family)
+    const int64_t rows_here = rows_end > row0 ? rows_end - row0 : 0;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + row0 * ldx), 0, (int)(rows_here * ldx * 4), kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(G + row0 * ldg), 0, (int)(rows_here * ldg * 4), kRsrcFlags);
+    uint32_t xoff[2], goff[4];
+    bool xin[2], gin[4];     // this piece's columns exist (whole pieces: K % 4 == F % 4 == 0)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        xin[p] = FULLC || m0 + xcol[p] < K;
+        xoff[p] = (uint32_t)(((int64_t)xnode[p] * ldx + (xin[p] ? m0 + xcol[p] : 0)) * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        gin[p] = FULLC || n0 + gcol[p] < F;
+        goff[p] = (uint32_t)(((int64_t)gnode[p] * ldg + (gin[p] ? n0 + gcol[p] : 0)) * 4);
+    }
+    const uint32_t xstep = (uint32_t)(TN_NODES * ldx * 4), gstep = (uint32_t)(TN_NODES * ldg * 4);
+    auto load_stage = [&](int s) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) rx[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[p], (uint32_t)s * xstep, 0));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) rg[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, goff[p], (uint32_t)s * gstep, 0));
+    };
+    int xo[2], go[4];   // LDS offsets of this thread's pieces inside a buffer
+#pragma unroll
+    for (int p = 0; p < 2; ++p) xo[p] = tn_off(xnode[p], xcol[p] >> 3) + (xcol[p] & 4) * 2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) go[p] = 2 * kPlaneX + (gcol[p] >> 7) * 2 * kPlaneX + tn_off(gnode[p], (gcol[p] & 127) >> 3) + (gcol[p] & 4) * 2;
+    auto write_stage = [&](int s) {   // registers of stage s -> planes of buffer s & 1
+        char *b = lds + (s & 1) * kTnBuf;
+        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            bf16x4 hi, lo;
+            split_bf16x4(FULLC || xin[p] ? rx[p] : zero, hi, lo);
+            *reinterpret_cast<bf16x4 *>(b + xo[p]) = hi;
+            *reinterpret_cast<bf16x4 *>(b + kPlaneX + xo[p]) = lo;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            bf16x4 hi, lo;
+            split_bf16x4(FULLC || gin[p] ? rg[p] : zero, hi, lo);
+            *reinterpret_cast<bf16x4 *>(b + go[p]) = hi;
+            *reinterpret_cast<bf16x4 *>(b + kPlaneX + go[p]) = lo;
+        }
+    };
+
+    f32x16 acc[4][RN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // lane offsets of the transposed reads inside a buffer: A = X plane image, column block i; B = this wavefront's two column
+    // tiles (columns 64 wave + 32 j of the 256: image (64 wave + 32 j) >> 7, block ((64 wave + 32 j) & 127) >> 5)
+    int aoff[4][2], boff[RN][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) aoff[i][hf] = tr_lane_off(i, hf, lane);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int col = 64 * wave + 32 * j;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) boff[j][hf] = 2 * kPlaneX + (col >> 7) * 2 * kPlaneX + tr_lane_off((col & 127) >> 5, hf, lane);
+    }
+    load_stage(0);
+    write_stage(0);
+    load_stage(1);   // (past the chunk: clamped addresses, never written to LDS)
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        const char *b = lds + (s & 1) * kTnBuf;
+        bf16x8 bh[RN], bl[RN], ah[2], al[2];
+        const unsigned lb = (unsigned)(size_t)b;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) tr_fragments(lb + boff[j][0], lb + boff[j][1], bh[j], bl[j]);
+        tr_fragments(lb + aoff[0][0], lb + aoff[0][1], ah[0], al[0]);
+        // The transposed reads are asm: the compiler does not count them, and nothing but a data dependency keeps an MFMA
+        // behind the wait -- so every fragment passes through an (empty) asm that follows its wait.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < RN; ++j) { asm volatile("" : "+v"(bh[j])); asm volatile("" : "+v"(bl[j])); }
+        asm volatile("" : "+v"(ah[0]));
+        asm volatile("" : "+v"(al[0]));
+        write_stage(s + 1);   // the other buffer: last read a stage ago, behind the barrier below (past the chunk: zeros, never read) --
+                              // unconditional: a branch here cuts the stage into basic blocks and nothing moves across them
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < 3)     // the next row block's fragments under this block's MFMAs
+                tr_fragments(lb + aoff[i + 1][0], lb + aoff[i + 1][1], ah[(i + 1) & 1], al[(i + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);   // small terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+            }
+            if (i < 3) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(ah[(i + 1) & 1]));
+                asm volatile("" : "+v"(al[(i + 1) & 1]));
+            }
+        }
+        load_stage(s + 2);   // (past the chunk: clamped, unused)
+        __syncthreads();
+    }
+
+    float *slab = slabs + (int64_t)split * K * F;
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int gn = n0 + 64 * wave + 32 * j + (lane & 31);
+        if (gn >= F) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gmb = m0 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = gmb + (r & 3) + 8 * (r >> 2);
+                if (gm < K) slab[(int64_t)gm * F + gn] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tn_slab_sum_kernel(const float *__restrict__ slabs, int n_slabs, int64_t kf, int F,
+                                                         float *__restrict__ dW, int64_t lddw)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= kf) return;
+    float s = 0.0f;
+    for (int z = 0; z < n_slabs; ++z) s += slabs[(int64_t)z * kf + i];  // fixed order
+    dW[(i / F) * lddw + (i % F)] = s;
+}
+
+struct TnPlan { int m_tiles, n_wg, n_splits; int64_t chunk_rows; size_t slab_bytes; };
+
+TnPlan tn_plan(int64_t N, int K, int F)
+{
+    TnPlan p;
+    p.m_tiles = (K + TN_BM - 1) / TN_BM;
+    p.n_wg = (F + TN_BN - 1) / TN_BN;
+    const int tiles = p.m_tiles * p.n_wg;
+    int per_xcd = 64 / tiles;          // chunks whose workgroups fit an XCD's 64 resident slots at once
+    if (per_xcd < 1) per_xcd = 1;
+    int64_t s = 8 * (int64_t)per_xcd;
+    const int64_t max_s = (N + 511) / 512;   // at least 512 node rows per chunk
+    if (s > max_s) s = max_s;
+    if (const char *e = getenv("GGCN_LAB_DW_SPLITS")) s = atoi(e);   // (development: tools/dw_timing.py)
+    if (s < 1) s = 1;
+    p.n_splits = (int)s;
+    const int64_t rows = (N + s - 1) / s;
+    p.chunk_rows = (rows + TN_NODES - 1) / TN_NODES * TN_NODES;
+    p.slab_bytes = (size_t)p.n_splits * K * F * sizeof(float);
+    return p;
+}
+
+}  // namespace
+
+bool dweight_tn_takes(const float *X, int64_t ldx, const float *G, int64_t ldg, int K, int F)
+{
+    return (ldx % 4 == 0) && (ldg % 4 == 0) && (K % 4 == 0) && (F % 4 == 0) && aligned16(X) && aligned16(G);
+}
+
+size_t dweight_tn_workspace_bytes(int64_t N, int K, int F)
+{
+    if (N <= 0 || K <= 0 || F <= 0) return 0;
+    return (tn_plan(N, K, F).slab_bytes + 255) & ~(size_t)255;
+}
+
+int dweight_tn(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F, float *dW, int64_t lddw,
+               void *workspace, hipStream_t st)
+{
+    const TnPlan p = tn_plan(N, K, F);
+    float *slabs = static_cast<float *>(workspace);
+    const int tiles = p.m_tiles * p.n_wg;
+    const int64_t grid = (int64_t)8 * tiles * ((p.n_splits + 7) / 8);
+    if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_dweight: too many tiles");
+    if ((p.chunk_rows + TN_NODES) * (ldx > ldg ? ldx : ldg) * 4 >= ((int64_t)1 << 31))
+        return fail(GGCN_EUNSUPPORTED, "ggcn_dweight: a chunk of %lld rows of %lld floats exceeds the 2 GiB a buffer resource addresses",
+                    (long long)p.chunk_rows, (long long)(ldx > ldg ? ldx : ldg));
+    if (K % TN_BM == 0 && F % TN_BN == 0)
+        hipLaunchKernelGGL(dweight_tn_kernel<true>, dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, G, ldg, N, K, F, slabs,
+                           p.chunk_rows, p.n_splits, p.m_tiles, p.n_wg);
+    else
+        hipLaunchKernelGGL(dweight_tn_kernel<false>, dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, G, ldg, N, K, F, slabs,
+                           p.chunk_rows, p.n_splits, p.m_tiles, p.n_wg);
+    const int64_t kf = (int64_t)K * F;
+    hipLaunchKernelGGL(tn_slab_sum_kernel, dim3((unsigned)((kf + 255) / 256)), dim3(256), 0, st, slabs, p.n_splits, kf, F, dW, lddw);
+    return check_launch("ggcn_dweight(bf16x3, TN)");
+}
+
+}  // namespace ggcn
