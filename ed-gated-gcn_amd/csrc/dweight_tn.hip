@@ -125,34 +125,39 @@ __global__ __launch_bounds__(kThreads, 2) void dweight_tn_kernel(const float *__
         goff[p] = (uint32_t)(((int64_t)gnode[p] * ldg + (gin[p] ? n0 + gcol[p] : 0)) * 4);
     }
     const uint32_t xstep = (uint32_t)(TN_NODES * ldx * 4), gstep = (uint32_t)(TN_NODES * ldg * 4);
+    auto load_x = [&](int s, int p) { rx[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[p], (uint32_t)s * xstep, 0)); };
+    auto load_g = [&](int s, int p) { rg[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, goff[p], (uint32_t)s * gstep, 0)); };
     auto load_stage = [&](int s) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) rx[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[p], (uint32_t)s * xstep, 0));
+        for (int p = 0; p < 2; ++p) load_x(s, p);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) rg[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, goff[p], (uint32_t)s * gstep, 0));
+        for (int p = 0; p < 4; ++p) load_g(s, p);
     };
     int xo[2], go[4];   // LDS offsets of this thread's pieces inside a buffer
 #pragma unroll
     for (int p = 0; p < 2; ++p) xo[p] = tn_off(xnode[p], xcol[p] >> 3) + (xcol[p] & 4) * 2;
 #pragma unroll
     for (int p = 0; p < 4; ++p) go[p] = 2 * kPlaneX + (gcol[p] >> 7) * 2 * kPlaneX + tn_off(gnode[p], (gcol[p] & 127) >> 3) + (gcol[p] & 4) * 2;
-    auto write_stage = [&](int s) {   // registers of stage s -> planes of buffer s & 1
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto write_x = [&](int s, int p) {   // register piece p of stage s -> planes of buffer s & 1
         char *b = lds + (s & 1) * kTnBuf;
-        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        bf16x4 hi, lo;
+        split_bf16x4(FULLC || xin[p] ? rx[p] : zero4, hi, lo);
+        *reinterpret_cast<bf16x4 *>(b + xo[p]) = hi;
+        *reinterpret_cast<bf16x4 *>(b + kPlaneX + xo[p]) = lo;
+    };
+    auto write_g = [&](int s, int p) {
+        char *b = lds + (s & 1) * kTnBuf;
+        bf16x4 hi, lo;
+        split_bf16x4(FULLC || gin[p] ? rg[p] : zero4, hi, lo);
+        *reinterpret_cast<bf16x4 *>(b + go[p]) = hi;
+        *reinterpret_cast<bf16x4 *>(b + kPlaneX + go[p]) = lo;
+    };
+    auto write_stage = [&](int s) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            bf16x4 hi, lo;
-            split_bf16x4(FULLC || xin[p] ? rx[p] : zero, hi, lo);
-            *reinterpret_cast<bf16x4 *>(b + xo[p]) = hi;
-            *reinterpret_cast<bf16x4 *>(b + kPlaneX + xo[p]) = lo;
-        }
+        for (int p = 0; p < 2; ++p) write_x(s, p);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            bf16x4 hi, lo;
-            split_bf16x4(FULLC || gin[p] ? rg[p] : zero, hi, lo);
-            *reinterpret_cast<bf16x4 *>(b + go[p]) = hi;
-            *reinterpret_cast<bf16x4 *>(b + kPlaneX + go[p]) = lo;
-        }
+        for (int p = 0; p < 4; ++p) write_g(s, p);
     };
 
     f32x16 acc[4][RN];
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(kThreads, 2) void dweight_tn_kernel(const float *__
     }
     load_stage(0);
     write_stage(0);
-    load_stage(1);   // (past the chunk: clamped addresses, never written to LDS)
+    load_stage(1);   // (past the chunk: zeros)
     __syncthreads();
     for (int s = 0; s < stages; ++s) {
         const char *b = lds + (s & 1) * kTnBuf;
@@ -194,25 +199,41 @@ __global__ __launch_bounds__(kThreads, 2) void dweight_tn_kernel(const float *__
         for (int j = 0; j < RN; ++j) { asm volatile("" : "+v"(bh[j])); asm volatile("" : "+v"(bl[j])); }
         asm volatile("" : "+v"(ah[0]));
         asm volatile("" : "+v"(al[0]));
-        write_stage(s + 1);   // the other buffer: last read a stage ago, behind the barrier below (past the chunk: zeros, never read) --
-                              // unconditional: a branch here cuts the stage into basic blocks and nothing moves across them
+        // The source order below IS the issue order (a sched_barrier after every group, as in the forward loops): each row
+        // block's six MFMAs carry a share of the next stage's split + LDS writes (the other buffer: last read a stage ago,
+        // behind the barrier below; unconditional -- past the chunk the pieces are zeros nobody reads) and, once a piece's
+        // registers are free, its global load two stages ahead.
+#define GGCN_SBT() __builtin_amdgcn_sched_barrier(0)
+        GGCN_SBT();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < 3)     // the next row block's fragments under this block's MFMAs
                 tr_fragments(lb + aoff[i + 1][0], lb + aoff[i + 1][1], ah[(i + 1) & 1], al[(i + 1) & 1]);
-#pragma unroll
-            for (int j = 0; j < RN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);   // small terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
-            }
+            GGCN_SBT();
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[0], acc[i][0], 0, 0, 0);   // small terms first
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[0], acc[i][0], 0, 0, 0);
+            GGCN_SBT();
+            if (i == 0) { write_x(s + 1, 0); write_x(s + 1, 1); }
+            if (i == 1) { write_g(s + 1, 0); write_g(s + 1, 1); }
+            if (i == 2) { write_g(s + 1, 2); write_g(s + 1, 3); }
+            GGCN_SBT();
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[1], acc[i][1], 0, 0, 0);
+            GGCN_SBT();
+            if (i == 0) { load_x(s + 2, 0); load_x(s + 2, 1); }   // (past the chunk: zeros from the buffer bounds, unused)
+            if (i == 1) { load_g(s + 2, 0); load_g(s + 2, 1); }
+            if (i == 2) { load_g(s + 2, 2); load_g(s + 2, 3); }
+            GGCN_SBT();
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[1], acc[i][1], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[1], acc[i][1], 0, 0, 0);
+            GGCN_SBT();
             if (i < 3) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(ah[(i + 1) & 1]));
                 asm volatile("" : "+v"(al[(i + 1) & 1]));
             }
         }
-        load_stage(s + 2);   // (past the chunk: clamped, unused)
+#undef GGCN_SBT
         __syncthreads();
     }
 
