@@ -65,6 +65,44 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
     const int W = (T + 31) >> 5;
     static_assert(WM == 1 && RN == 2, "written for 128 x 64 wavefront tiles");
 
+    // ---- the edge lists of the graph's rows (what the epilogue's neighbour sums walk), made BEFORE the main loop: their LDS
+    // lies behind both row groups' stage buffers, and the row masks' trip from global memory hides under the loop's first
+    // stages instead of standing between the loop and the epilogue ----
+    if constexpr (!GGCN_LAB_WIDE8_DENSE) {
+        unsigned short *s_ids = reinterpret_cast<unsigned short *>(lds8 + kW8Ex + 4096);   // [256 rows][kW8Cap]
+        int *s_deg = reinterpret_cast<int *>(lds8 + kW8Ex + 4096 + 256 * kW8Cap * 2);      // [256]
+        float *s_inv = reinterpret_cast<float *>(lds8 + kW8Ex + 4096 + 256 * kW8Cap * 2 + 1024);   // [256] 1 / (deg + 1)
+        const int zero_off = kW8Ex + 4096 + 256 * kW8Cap * 2 + 2048;                         // 128 B of zeros
+        auto tile_off = [](int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); };
+        // thread t < 256: row t
+        if (tid < 256) {
+            const int row = tid;
+            uint32_t mwd[8];
+#pragma unroll
+            for (int wi = 0; wi < 8; ++wi) {
+                const bool ok = row < T && wi < W && !((GGCN_LAB_OFF) & 32);   // (timing build: no masks, empty lists)
+                const uint32_t v = a.rowmask[ok ? ((int64_t)g * T + row) * W + wi : 0];
+                mwd[wi] = ok ? v : 0u;
+            }
+            int deg = 0, e = 0;
+#pragma unroll
+            for (int wi = 0; wi < 8; ++wi) {
+                uint32_t w = mwd[wi];
+                deg += __popc(w);
+                while (w && e < kW8Cap) {   // stored: the source row's byte offset in a tile (chunk 0; a lane XORs its 16 cl in)
+                    s_ids[row * kW8Cap + e++] = (unsigned short)tile_off(32 * wi + __builtin_ctz(w), 0);
+                    w &= w - 1;
+                }
+            }
+            // the rest of the list points at row 255: a padding row for T < 256, all zeros in every tile (its X row was staged as
+            // zeros), so the sums need no test per slot; T = 256 has no such row and masks the slots instead
+            for (; e < kW8Cap; ++e) s_ids[row * kW8Cap + e] = (unsigned short)tile_off(255, 0);
+            s_deg[row] = deg;
+            s_inv[row] = 1.0f / (float)(deg + 1);                               // gcn.py:35
+            if (tid < 32) reinterpret_cast<float *>(lds8 + zero_off)[tid] = 0.0f;
+        }
+    }
+
     // ---- hidden = X . W for both row groups at once ----
     constexpr int NP = Geom<float>::NP;
     f32x16 acc[4][RN];
@@ -326,33 +364,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
     // 16-byte chunk `chunk` of row `row`: the 64-byte half is flipped on rows 2, 3 (mod 4), so that the four 8-lane groups a
     // ds_read_b128 serves together (two read chunks 0-3, two chunks 4-7 of their rows) collide on one row pair in four
     auto tile_off = [](int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); };
-    // edge lists of the graph's rows, once per workgroup (thread t < 256: row t)
-    if (tid < 256) {
-        const int row = tid;
-        uint32_t mwd[8];
-#pragma unroll
-        for (int wi = 0; wi < 8; ++wi) {
-            const bool ok = row < T && wi < W && !((GGCN_LAB_OFF) & 32);   // (timing build: no masks, empty lists)
-            const uint32_t v = a.rowmask[ok ? ((int64_t)g * T + row) * W + wi : 0];
-            mwd[wi] = ok ? v : 0u;
-        }
-        int deg = 0, e = 0;
-#pragma unroll
-        for (int wi = 0; wi < 8; ++wi) {
-            uint32_t w = mwd[wi];
-            deg += __popc(w);
-            while (w && e < kW8Cap) {   // stored: the source row's byte offset in a tile (chunk 0; a lane XORs its 16 cl in)
-                s_ids[row * kW8Cap + e++] = (unsigned short)tile_off(32 * wi + __builtin_ctz(w), 0);
-                w &= w - 1;
-            }
-        }
-        // the rest of the list points at row 255: a padding row for T < 256, all zeros in every tile (its X row was staged as
-        // zeros), so the sums need no test per slot; T = 256 has no such row and masks the slots instead
-        for (; e < kW8Cap; ++e) s_ids[row * kW8Cap + e] = (unsigned short)tile_off(255, 0);
-        s_deg[row] = deg;
-        s_inv[row] = 1.0f / (float)(deg + 1);                               // gcn.py:35
-        if (tid < 32) reinterpret_cast<float *>(lds8 + zero_off)[tid] = 0.0f;
-    }
+    // (the edge lists of the graph's rows were made before the main loop: see there)
     float vmax[RN][4], vmin[RN][4];
 #pragma unroll
     for (int j = 0; j < RN; ++j)

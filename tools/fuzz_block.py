@@ -16,7 +16,7 @@ for it in range(cases):
     T = int(rng.integers(1, 33))
     B = int(rng.integers(1, 40))
     H = int(rng.choice([32, 64, 96, 100, 128, 256, 260]))
-    prec = str(rng.choice(["f16mx8", "f16mx6", "bf16x3"]))
+    prec = str(rng.choice(["f16mx8", "f16mx6", "bf16x3"] if pkg._capi.has_f16mx6() else ["f16mx8", "bf16x3"]))
     lens = np.array([T] + [int(v) for v in rng.integers(1, T + 1, size=B - 1)])
     adj = synth.dependency_batch(B, T, min(4.0, T), seed=int(rng.integers(1 << 30)), lengths=lens).astype(np.float32)
     x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32))
