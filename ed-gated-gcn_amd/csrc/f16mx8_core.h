@@ -199,6 +199,11 @@ __device__ __forceinline__ BufX<AT> make_bufx(const AT *X, int64_t ldx, int64_t 
 // NB (fp32 rows: one staging pass = one 32-row block): only the first NB of this wavefront's four blocks exist at all -- the
 // staging passes, fragment reads and MFMAs of the others are not compiled in (the second row group of a 129..224-node graph
 // in a 256-row slot, fused_wide8.hip): their LDS rows are never written or read, their accumulators stay zero.
+// W2 (GGCN_LAB_W2, lab): a second register set for W's fp16 fragments -- the next stage's are asked for at the TOP of a
+// stage (a whole stage of lead) instead of behind its first MX MFMA (7 MFMAs of lead).
+#ifndef GGCN_LAB_W2
+#define GGCN_LAB_W2 0
+#endif
 template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false, bool BUF = false, int NB = 4>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int stages_packed, int wm,
@@ -377,7 +382,9 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    f16x8 b0[RN], b1[RN];
+    constexpr bool W2 = (GGCN_LAB_W2) != 0;
+    f16x8 bset0[W2 ? 2 : 1][RN], bset1[W2 ? 2 : 1][RN];   // fp16 fragments of the two k-steps: [register set][column tile]
+    f16x8 (&b0)[RN] = bset0[0], (&b1)[RN] = bset1[0];
     i32x4 bq[RN];  // fp8(wl) of the stage
     i32x4 bw[RN];  // fp8(wh) of the stage (GGCN_WH8_STORED)
     int sq[RN];
@@ -432,6 +439,10 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         i32x8 aq[2];
         if GGCN_ON(8) read_h(buf, 0, ah[0]); else { ah[0][0] = lab_h[0]; ah[0][1] = lab_h[1]; }
         if GGCN_ON(16) { load_bq(kstage(st), bq, sq); if constexpr (GGCN_WH8_STORED) load_wh8(kstage(st), bw); }
+        // W2: this stage's fragments live in set `buf` (stage parity = buffer parity); the next stage's are asked for now, BEHIND
+        // this stage's bq (vmcnt retires in order: the MX phase's wait for bq must not wait for them)
+        f16x8 (&b0)[RN] = bset0[W2 ? buf : 0], (&b1)[RN] = bset1[W2 ? buf : 0];
+        if constexpr (W2) { if GGCN_ON(16) load_bf(kstage(st + 1), bset0[buf ^ 1], bset1[buf ^ 1]); }
         GGCN_SB();
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -485,7 +496,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[0], acc[i][0], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[0]);
             GGCN_SB();
             if constexpr (GGCN_LAB_WH8) { if (i == 0) make_bm(1); }
-            if GGCN_ON(16) { if (i == 0) load_bf(kstage(st + 1), b0, b1); }  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
+            if constexpr (!W2) { if GGCN_ON(16) { if (i == 0) load_bf(kstage(st + 1), b0, b1); } }  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[1], acc[i][1], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[1]);
             GGCN_SB();
