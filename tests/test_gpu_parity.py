@@ -1318,6 +1318,18 @@ def test_bench_distributed_loop_over_rccl_with_a_process_group_of_one(pkg, dev):
     assert r["value"] > 0 and "roofline" in r
 
 
+def test_range_report_reaches_a_process_that_never_asks(pkg, dev):
+    """the lazy report needs a LATER forward to surface; a process with a single forward (or none after the
+    violation) used to exit silently.  Now the snapshot is taken behind the first guarded forward and whatever is still
+    unreported at interpreter exit is printed to stderr (tools/exit_probe.py: one forward with |x| ~ 1000, no check)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "exit_probe.py")], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "forward done" in out.stdout
+    assert "448" in out.stderr and "bf16x3" in out.stderr, out.stderr[-2000:]
+
+
 # ---------------------------------------------------------------- the drop-in forward(text, adj): syncs, cache, defaults
 def test_dropin_forward_is_sync_free_and_shares_the_conversion(pkg, dev):
     """models/gcn.py:30-45 has no device synchronisation; neither has forward(text, dense adj) here when the
