@@ -26,9 +26,11 @@ PROTOTYPES = {
     "ggcn_csr_rowmask": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_graph_operands_bytes": (c_sz, [c_i32]),
     "ggcn_graph_operands": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "ggcn_graph_operands2_bytes": (c_sz, [c_i32]),
+    "ggcn_graph_operands2": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_layer_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                  c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
-    "ggcn_block_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+    "ggcn_block_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                  c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "ggcn_overlap_reduce": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_transpose": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_vp]),
@@ -67,7 +69,7 @@ PROTOTYPES = {
     "ggcn_gate_overlap": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2, "f16": 3, "f16mx6": 4}
 PACKED = ("bf16x3", "f16mx8", "f16", "f16mx6")  # precisions whose linear reads a ggcn_weight_pack image ("f16": half features only)
 FLAG_WEIGHTED = 1

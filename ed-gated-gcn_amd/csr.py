@@ -61,7 +61,7 @@ class BatchedCSR:
     kernel: all the fused layer needs); the CSR arrays are materialised on first access."""
 
     __slots__ = ("_rowptr", "_colidx", "_vals", "rowmask", "B", "T", "nnz", "is_binary",
-                 "_dense", "_dense_version", "_t", "_inv", "_graph_ops", "__weakref__")
+                 "_dense", "_dense_version", "_t", "_inv", "_graph_ops", "_graph_ops2", "__weakref__")
 
     def __init__(self, rowptr, colidx, vals, B, T, nnz=None, rowmask=None):
         self._rowptr, self._colidx, self._vals, self.rowmask = rowptr, colidx, vals, rowmask
@@ -72,6 +72,7 @@ class BatchedCSR:
         self._t = None       # cached CSR of the transposed adjacency (backward pass)
         self._inv = None     # cached 1/(rowsum+1) per node
         self._graph_ops = None   # cached ggcn_graph_operands blocks (T <= 32)
+        self._graph_ops2 = None  # cached ggcn_graph_operands2 blocks per plane type (the one-launch block)
 
     @property
     def graph_ops(self):
@@ -86,6 +87,25 @@ class BatchedCSR:
                                                     _capi.stream_of(dev)), "ggcn_graph_operands")
             self._graph_ops = ops
         return self._graph_ops
+
+    def graph_ops2(self, plane):
+        """uint8 [B * GGCN_GRAPH_OPS2_BYTES]: the block's second layer as ONE operand per graph -- (D.A)^2 in the plane type
+        of the launch (0 = bf16 pairs for "bf16x3", 1 = fp16 pairs for "f16mx8" / "f16mx6") -- built from the row masks on
+        first use (``ggcn_graph_operands2``), one per plane type."""
+        store = self._graph_ops2
+        if store is None:
+            store = self._graph_ops2 = {}
+        if plane not in store:
+            if self.rowmask is None or self.T > 32 or not self.rowmask.is_cuda:
+                return None
+            lib = _capi.load_library()
+            dev = self.rowmask.device
+            ops = torch.empty(lib.ggcn_graph_operands2_bytes(self.B), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _capi.check(lib.ggcn_graph_operands2(_capi.ptr(self.rowmask), self.B, self.T, plane, _capi.ptr(ops),
+                                                     _capi.stream_of(dev)), "ggcn_graph_operands2")
+            store[plane] = ops
+        return store[plane]
 
     @property
     def device(self):

@@ -72,6 +72,11 @@ int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
 }
 
 size_t ggcn_graph_operands_bytes(int B) { return B > 0 ? (size_t)B * GGCN_GRAPH_OPS_BYTES : 0; }
+size_t ggcn_graph_operands2_bytes(int B) { return B > 0 ? (size_t)B * GGCN_GRAPH_OPS2_BYTES : 0; }
+int ggcn_graph_operands2(const uint32_t *rowmask, int B, int T, int plane, void *graph_ops2, ggcn_stream_t stream)
+{
+    return graph_operands2(rowmask, B, T, plane, graph_ops2, as_stream(stream));
+}
 
 int ggcn_graph_operands(const uint32_t *rowmask, int B, int T, void *graph_ops, ggcn_stream_t stream)
 {
@@ -89,12 +94,12 @@ int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint3
 }
 
 int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
-                     const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
+                     const void *graph_ops2, const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
                      const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
                      float *x1, float *y1, float *pool_out, float *overlap_partial, int precision,
                      ggcn_stream_t stream)
 {
-    return block_fused(X, ldx, wpack1, wpack12, graph_ops, bias1, bias_mid, bias2, B, T, K, F, gate1, gate2, gcn1, ld1,
+    return block_fused(X, ldx, wpack1, wpack12, graph_ops, graph_ops2, bias1, bias_mid, bias2, B, T, K, F, gate1, gate2, gcn1, ld1,
                        x_out, ld2, x1, y1, pool_out, overlap_partial, precision, as_stream(stream));
 }
 

@@ -69,6 +69,7 @@ int subword_pool(const float *A, int64_t sa_b, int64_t sa_r, int64_t sa_c, const
                  int64_t ldx, float *Y, int64_t y_batch, int64_t ldy, int B, int R, int C, int D, hipStream_t st);
 int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask, hipStream_t st);
 int graph_operands(const uint32_t *rowmask, int B, int T, void *ops, hipStream_t st);
+int graph_operands2(const uint32_t *rowmask, int B, int T, int plane, void *ops2, hipStream_t st);
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops, const float *bias,
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,
@@ -76,7 +77,7 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
                 const struct DropSpec *drop = nullptr);
 int dropout_mask(int64_t rows, int F, float p, uint64_t seed, int sel, float *out, hipStream_t st);
 
-int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
+int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops, const void *graph_ops2,
                 const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
                 const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
                 float *x1, float *y1, float *pool_out, float *overlap_partial, int precision, hipStream_t st);

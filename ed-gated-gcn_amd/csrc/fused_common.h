@@ -28,6 +28,7 @@ struct FusedArgs {
     int64_t ldx;
     const uint32_t *rowmask;    // graphs of 33..256 nodes (layer_fused_wide_kernel)
     const char *graph_ops;      // graphs of <= 32 nodes: ggcn_graph_operands blocks (layer_fused_kernel)
+    const char *graph_ops2;     // the block's W12 tiles: ggcn_graph_operands2 blocks ((D.A)^2 in the launch's plane type)
     const float *ov_in;         // partials an EARLIER launch wrote: block 0 reduces them to *ov_out first
     float *ov_out;
     int B, T, K, F;
@@ -131,6 +132,13 @@ __device__ __forceinline__ f32x16 adj_times(const bf16x8 (&af)[2], const f32x16 
 // graph were ~45 VALU + 16 LDS operations per graph and wavefront: a tenth of the epilogue's instructions).
 constexpr int kOpsBytes = GGCN_GRAPH_OPS_BYTES;
 static_assert(kOpsBytes == 2048 + 128, "layout above");
+// ggcn_graph_operands2 (the block's second layer, MID): M2 = (D.A)^2 * 2^10 as A-operand fragments in the plane type
+//   [0, 1024) hi part, k-step 0;  [1024, 2048) hi, k-step 1;  [2048, 3072) lo, k-step 0;  [3072, 4096) lo, k-step 1
+//   (lane l at 16 l; element j <-> node 16s + 8(j>>2) + 4h + (j&3) as above)
+//   [4096, 4224) rowsum(D.A) = deg / (deg + 1) in accumulator order: float [h][16]
+constexpr int kOps2Bytes = GGCN_GRAPH_OPS2_BYTES;
+static_assert(kOps2Bytes == 4096 + 128, "layout above");
+constexpr float kM2Scale = 1024.0f, kM2InvScale = 1.0f / 1024.0f;
 
 
 // acc -> two fp16 planes (hi = RNE fp16(v), lo = fp16(v - hi): residual <= 2^-22 |v| + 2^-25, fp16 subnormals are kept
@@ -201,12 +209,12 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
 template <int BASE>
 struct EpiLds {   // byte offsets of the staged operands; the store staging of the epilogue is always [0, 32 KiB)
     static constexpr int kOps = BASE;
-    static constexpr int kGate = kOps + 4 * kOpsBytes;
+    static constexpr int kGate = kOps + 4 * kOps2Bytes;   // (the W12 tiles of the block stage the larger (D.A)^2 blocks)
     static constexpr int kBias = kGate + 3 * 4 * BN * 4;
     static constexpr int kMidMax = kBias + 2 * BN * 4;   // 4 floats: max |mid bias| per wavefront (the hidden-value bound of the range flag)
     static constexpr int kEnd = kMidMax + 16;
 };
-constexpr int kEpiLdsBytes = EpiLds<0>::kEnd;   // 8704 + 12288 + 2048 + 16 = 23056
+constexpr int kEpiLdsBytes = EpiLds<0>::kEnd;   // 16896 + 12288 + 2048 + 16 = 31248
 static_assert(WM == 1, "one wavefront row: the workgroup's 4 graphs are every wavefront's 4 graphs");
 
 template <int BASE>
@@ -214,17 +222,21 @@ __device__ __forceinline__ void stage_epilogue_operands(const FusedArgs &a, cons
 {
     constexpr int kEpiOps = EpiLds<BASE>::kOps, kEpiGate = EpiLds<BASE>::kGate, kEpiBias = EpiLds<BASE>::kBias;
     const int B = a.B, F = a.F;
-    // operand blocks: 544 pieces of 16 B
-    uint4 piece[3];
-    const int n_pieces = 4 * kOpsBytes / 16;
+    // operand blocks: 544 pieces of 16 B (a layer, layer 1 of the block) or 1056 (the block's W12 tiles: (D.A)^2)
+    constexpr int kPieceIts = (4 * kOps2Bytes / 16 + kThreads - 1) / kThreads;   // 5
+    uint4 piece[kPieceIts];
+    const bool second = lp.mid != nullptr;   // workgroup-uniform
+    const int blk_bytes = second ? kOps2Bytes : kOpsBytes;
+    const char *ops_src = second ? a.graph_ops2 : a.graph_ops;
+    const int n_pieces = 4 * blk_bytes / 16;
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < kPieceIts; ++it) {
         const int idx = tid + it * kThreads;
         const int idc = idx < n_pieces ? idx : 0;
-        const int gi = (idc * 16) / kOpsBytes;
+        const int gi = (idc * 16) / blk_bytes;
         // a graph past the batch reads graph g0's bytes instead (never used)
-        const int64_t off = (int64_t)g0 * kOpsBytes + (g0 + gi < B ? idc * 16 : idc * 16 - gi * kOpsBytes);
-        piece[it] = *reinterpret_cast<const uint4 *>(a.graph_ops + off);
+        const int64_t off = (int64_t)g0 * blk_bytes + (g0 + gi < B ? idc * 16 : idc * 16 - gi * blk_bytes);
+        piece[it] = *reinterpret_cast<const uint4 *>(ops_src + off);
     }
     // gates and biases of this workgroup's 256 columns
     const int col = n_wgi * BN + tid;
@@ -243,7 +255,7 @@ __device__ __forceinline__ void stage_epilogue_operands(const FusedArgs &a, cons
     const float vbias = (lp.bias ? lp.bias : dummy)[lp.bias && cok ? col : 0];
     const float vmidb = (lp.mid ? lp.mid : dummy)[lp.mid && cok ? col : 0];
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < kPieceIts; ++it) {
         const int idx = tid + it * kThreads;
         if (idx < n_pieces) *reinterpret_cast<uint4 *>(lds + kEpiOps + idx * 16) = piece[it];
     }
@@ -262,9 +274,10 @@ __device__ __forceinline__ void stage_epilogue_operands(const FusedArgs &a, cons
     // visible to every wavefront after the main loop's first barrier
 }
 
-// The sticky range flag of the fp16-plane epilogue (f16mx8_core.h): |hidden[r,f]| <= max_k |x[r,k]| * sum_k |w[k,f]|, and the
-// second aggregation of the block's W12 tiles adds at most max |mid|; every element of the tile is split by exactly one
-// lane, so the lane that owns a row's largest element speaks for the row.  pack_bytes: size of the image without its trailer.
+// The sticky range flag of the fp16-plane epilogue (f16mx8_core.h): |hidden[r,f]| <= max_k |x[r,k]| * sum_k |w[k,f]| is all the
+// epilogue rounds to fp16 (the block's W12 tiles included: one application of (D.A)^2 to X.W12; max |mid| stays in the
+// bound as slack); every element of the tile is split by exactly one lane, so the lane that owns a row's largest element
+// speaks for the row.  pack_bytes: size of the image without its trailer.
 template <int BASE>
 __device__ __forceinline__ void fused_range_verdict(float amax, const char *wpack, int64_t pack_bytes, const char *lds, bool window)
 {
@@ -358,19 +371,33 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
     for (int i = 0; i < 4; ++i) {
         const int g = g0 + i;
         if (!FULLT && g >= B) break;  // workgroup-uniform
-        // adjacency fragments of graph g: the stored 0xFFFF elements become the plane type's 1.0
-        frag afv[2];
+        // the graph's operands out of LDS.  A layer / layer 1 of the block: the adjacency as 0xFFFF elements (one AND with the
+        // plane type's 1.0 makes the exact A operand) + 1 / (rowsum + 1).  MID (layer 2 of the block through W12 = W1.W2):
+        // M2 = (D.A)^2 * 2^10 as hi and lo fragments + rowsum(D.A) -- D.A.(D.A.H + 1.mid^T) + 1.b^T = M2.H + rowsum(D.A).mid^T
+        // + 1.b^T: ONE split of H and 6 MFMAs (M2hi.Hhi, M2hi.Hlo, M2lo.Hhi; the lo.lo term is 2^-22 of the result) where the
+        // two applications took two splits, an intermediate normalise pass and 8 MFMAs.
+        constexpr int kBlk = MID ? kOps2Bytes : kOpsBytes;
+        constexpr int kRowOff = MID ? 4096 : 2048;
+        frag afv[2], afl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const uint4 raw = *reinterpret_cast<const uint4 *>(ops_lds + i * kOpsBytes + s * 1024 + lane * 16);
+            const uint4 raw = *reinterpret_cast<const uint4 *>(ops_lds + i * kBlk + s * 1024 + lane * 16);
             union { frag v; uint32_t w[4]; } u;
-            u.w[0] = raw.x & P::kOne; u.w[1] = raw.y & P::kOne;
-            u.w[2] = raw.z & P::kOne; u.w[3] = raw.w & P::kOne;
-            afv[s] = u.v;
+            if constexpr (MID) {
+                u.w[0] = raw.x; u.w[1] = raw.y; u.w[2] = raw.z; u.w[3] = raw.w;
+                afv[s] = u.v;
+                const uint4 rl = *reinterpret_cast<const uint4 *>(ops_lds + i * kBlk + 2048 + s * 1024 + lane * 16);
+                u.w[0] = rl.x; u.w[1] = rl.y; u.w[2] = rl.z; u.w[3] = rl.w;
+                afl[s] = u.v;
+            } else {
+                u.w[0] = raw.x & P::kOne; u.w[1] = raw.y & P::kOne;
+                u.w[2] = raw.z & P::kOne; u.w[3] = raw.w & P::kOne;
+                afv[s] = u.v;
+            }
         }
         float4 rv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4 *>(ops_lds + i * kOpsBytes + 2048 + h * 64 + q * 16);
+        for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4 *>(ops_lds + i * kBlk + kRowOff + h * 64 + q * 16);
         float vsg[RN], vga[RN], vgb[RN];
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
@@ -383,7 +410,7 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
 #pragma unroll
         for (int j = 0; j < RN; ++j) tile_ok[j] = nt0 + j < n_tiles_total;   // wavefront-uniform: column tile past F
 
-        // gcn.py:41 (layer 1 / the layer): agg = ADJ_g . hidden_g, small plane first; the column tiles' chains are
+        // gcn.py:41: agg = ADJ_g . hidden_g (MID: M2_g . hidden_g), small terms first; the column tiles' chains are
         // issued one behind the other, so that a tile's split and element-wise work sit under the other's MFMAs
         f32x16 y[RN];
 #pragma unroll
@@ -392,31 +419,26 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
             P::split(acc[i][j], hf);
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[j][r] = 0.0f;
+            if constexpr (MID) {
 #pragma unroll
-            for (int p = 1; p >= 0; --p)
+                for (int s = 0; s < 2; ++s) y[j] = P::mma(afl[s], hf[0][s], y[j]);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) { if constexpr (!((GGCN_LAB_EPI) & 2)) y[j] = P::mma(afv[s], hf[p][s], y[j]); else y[j][s] += (float)hf[p][s][0]; }
+                for (int s = 0; s < 2; ++s) y[j] = P::mma(afv[s], hf[1][s], y[j]);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) y[j] = P::mma(afv[s], hf[0][s], y[j]);
+            } else {
+#pragma unroll
+                for (int p = 1; p >= 0; --p)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) { if constexpr (!((GGCN_LAB_EPI) & 2)) y[j] = P::mma(afv[s], hf[p][s], y[j]); else y[j][s] += (float)hf[p][s][0]; }
+            }
         }
+        // per row: the factor of the aggregate and what is added to it.  A layer: 1 / (rowsum + 1) and the bias (gcn.py:41,43);
+        // MID: 2^-10 (M2's scale) and rowsum(D.A) * mid + bias
         float rinv[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             rinv[4 * q] = rv[q].x; rinv[4 * q + 1] = rv[q].y; rinv[4 * q + 2] = rv[q].z; rinv[4 * q + 3] = rv[q].w;
-        }
-        if constexpr (MID) {   // the block's second layer through W12 = W1.W2 (header): D.A.(X.W12) + c, then gcn.py:41 again
-#pragma unroll
-            for (int j = 0; j < RN; ++j) {
-                f32x16 u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) u[r] = y[j][r] * rinv[r] + vmid[j];
-                frag hf[2][2];
-                P::split(u, hf);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) y[j][r] = 0.0f;
-#pragma unroll
-                for (int p = 1; p >= 0; --p)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) y[j] = P::mma(afv[s], hf[p][s], y[j]);
-            }
         }
         float dot = 0.0f;  // this wavefront's share of sum_f x1[g,f] * y1[g,f] (bert_amir5.py:638)
 #pragma unroll
@@ -436,7 +458,7 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row0 = (r & 3) + 8 * (r >> 2);  // this lane's row is row0 + 4h
-                const float v = y[j][r] * rinv[r] + bj;   // gcn.py:41,43
+                const float v = MID ? fmaf(y[j][r], kM2InvScale, fmaf(rinv[r], vmid[j], bj)) : y[j][r] * rinv[r] + bj;   // gcn.py:41,43
                 float vs = v * sg;
                 if constexpr (DROP) {
                     const uint32_t hh = drop_hash(didx0 + (uint32_t)(row0 * F), a.drop.seed_lo, a.drop.seed_hi);

@@ -67,6 +67,64 @@ __global__ __launch_bounds__(256) void graph_operands_kernel(const uint32_t *__r
     if (lane < 32) reinterpret_cast<float *>(blk + 2048)[lane] = 1.0f / (float)(__popc(mrow) + 1);
 }
 
+// ggcn_graph_operands2: M2 = (D.A)^2 per graph, scaled by 2^10, as hi / lo A-operand fragments of the plane type (layout:
+// fused_common.h), and rowsum(D.A).  One wavefront per graph; lane (r, h) owns row r and the 16 columns its fragments hold:
+//   M2[r][c] = 1/(deg_r + 1) * sum_{j in N(r)} A[j][c] / (deg_j + 1)          (fp32, j ascending)
+template <int PLANE>   // 0: bf16 pairs (GGCN_PREC_BF16X3), 1: fp16 pairs (GGCN_PREC_F16MX8)
+__global__ __launch_bounds__(256) void graph_operands2_kernel(const uint32_t *__restrict__ rowmask, int B, int T,
+                                                              char *__restrict__ ops2)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= B) return;   // wavefront-uniform
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t m = r < T ? rowmask[(int64_t)g * T + r] : 0u;   // T <= 32: one word per node; lanes r and r + 32 hold row r
+    const float inv_r = 1.0f / (float)(__popc(m) + 1);             // gcn.py:35
+    float a2[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a2[s][e] = 0.0f;
+    for (int j = 0; j < T; ++j) {   // wavefront-uniform walk over the possible neighbours
+        const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);   // row j's mask
+        const float invj = 1.0f / (float)(__popc(mj) + 1);
+        if ((m >> j) & 1u) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
+                    a2[s][e] += ((mj >> c) & 1u) ? invj : 0.0f;
+                }
+        }
+    }
+    char *blk = ops2 + (int64_t)g * kOps2Bytes;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        union { uint4 q; unsigned short u[8]; } hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = a2[s][e] * inv_r * kM2Scale;
+            if constexpr (PLANE == 1) {
+                const _Float16 vh = (_Float16)v, vl = (_Float16)(v - (float)vh);
+                hi.u[e] = __builtin_bit_cast(unsigned short, vh);
+                lo.u[e] = __builtin_bit_cast(unsigned short, vl);
+            } else {
+                const __bf16 vh = (__bf16)v, vl = (__bf16)(v - (float)vh);
+                hi.u[e] = __builtin_bit_cast(unsigned short, vh);
+                lo.u[e] = __builtin_bit_cast(unsigned short, vl);
+            }
+        }
+        *reinterpret_cast<uint4 *>(blk + s * 1024 + lane * 16) = hi.q;
+        *reinterpret_cast<uint4 *>(blk + 2048 + s * 1024 + lane * 16) = lo.q;
+    }
+    // rowsum(D.A) = deg / (deg + 1) in accumulator order: lane idx (0..31) writes entry [h' = idx >> 4][r' = idx & 15]
+    const int rr = lane & 15, hh = (lane >> 4) & 1;
+    const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+    const uint32_t mrow = __shfl(m, row);
+    if (lane < 32) reinterpret_cast<float *>(blk + 4096)[lane] = (float)__popc(mrow) / (float)(__popc(mrow) + 1);
+}
+
 // SCH: 0 = bf16x3 main loop, 1 = f16mx8 (f16mx8_core.h)
 // FULLT: T == 32 and B % 4 == 0 (every row of every tile is a real node): drops every guard.
 // VST: the [N,F] output leaves through LDS as 16-byte row stores (needs F, ldo multiples of 4 and a 16-byte aligned out)
@@ -367,6 +425,19 @@ int graph_operands(const uint32_t *rowmask, int B, int T, void *ops, hipStream_t
     return check_launch("ggcn_graph_operands");
 }
 
+int graph_operands2(const uint32_t *rowmask, int B, int T, int plane, void *ops2, hipStream_t st)
+{
+    if (!rowmask || !ops2) return fail(GGCN_EINVAL, "ggcn_graph_operands2: null pointer");
+    if (B <= 0 || T <= 0) return fail(GGCN_EINVAL, "ggcn_graph_operands2: B=%d T=%d must be positive", B, T);
+    if (T > 32) return fail(GGCN_EUNSUPPORTED, "ggcn_graph_operands2: T=%d > 32 (the two-layer block takes graphs of <= 32 nodes)", T);
+    if (plane != 0 && plane != 1) return fail(GGCN_EINVAL, "ggcn_graph_operands2: plane %d (0 = bf16 pairs, 1 = fp16 pairs)", plane);
+    if (!aligned16(ops2)) return fail(GGCN_EINVAL, "ggcn_graph_operands2: ops2 must be 16-byte aligned");
+    const dim3 grid((unsigned)((B + 3) / 4));
+    if (plane == 1) hipLaunchKernelGGL(graph_operands2_kernel<1>, grid, dim3(256), 0, st, rowmask, B, T, static_cast<char *>(ops2));
+    else hipLaunchKernelGGL(graph_operands2_kernel<0>, grid, dim3(256), 0, st, rowmask, B, T, static_cast<char *>(ops2));
+    return check_launch("ggcn_graph_operands2");
+}
+
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops,
                 const float *bias, int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,
@@ -387,7 +458,7 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
 }
 
 int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
-                const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
+                const void *graph_ops2, const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
                 const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
                 float *x1, float *y1, float *pool_out, float *overlap_partial, int precision, hipStream_t st)
 {
@@ -397,7 +468,9 @@ int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpa
     if ((gcn1 && ld1 > (int64_t)INT32_MAX) || (x_out && ld2 > (int64_t)INT32_MAX))
         return fail(GGCN_EUNSUPPORTED, "ggcn_block_fused: leading dimension too large");
     FusedArgs a = {};
-    a.X = X; a.ldx = ldx; a.graph_ops = static_cast<const char *>(graph_ops);
+    if (!graph_ops2 || !aligned16(graph_ops2))
+        return fail(GGCN_EINVAL, "ggcn_block_fused: graph_ops2 (ggcn_graph_operands2 blocks, 16-byte aligned) is required");
+    a.X = X; a.ldx = ldx; a.graph_ops = static_cast<const char *>(graph_ops); a.graph_ops2 = static_cast<const char *>(graph_ops2);
     a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = 2;
     // bert_amir5.py:626-636: gcn1 (ungated; optional here), x1 = max_t gcn1*gate1, y1 = max_t gcn1*gate2
     a.part[0] = LayerPart{static_cast<const char *>(wpack1), bias1, nullptr, nullptr, gate1, gate2,

@@ -40,7 +40,8 @@ def _block_operands(gc1, gc2, lib, st, precision=None):
     * packed ``W1`` (gc1's own image), packed ``W12 = W1 . W2`` and ``mid = W2^T . b1``.
 
     ``bert_amir5.py:626,639`` feed gc2 with the UNGATED gcn1 and ``gcn.py:30-45`` applies no non-linearity,
-    so ``gc2(gc1(x)) = D.A.(D.A.(x.W12) + mid) + b2``.  W12 and mid come from the library's exact-fp32 MFMA
+    so ``gc2(gc1(x)) = D.A.(D.A.(x.W12) + mid) + b2 = (D.A)^2.(x.W12) + rowsum(D.A).mid + b2`` (the launch applies the
+    graph's precomputed ``(D.A)^2``: ``BatchedCSR.graph_ops2``).  W12 and mid come from the library's exact-fp32 MFMA
     linear (a k-ordered fp32 FMA chain): they are parameters folded once per weight update, not activations."""
     w1, w2, b1 = gc1.weight, gc2.weight, gc1.bias
     precision = precision or gc1.precision
@@ -123,7 +124,8 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
             b1 = None if gc1.bias is None else gc1.bias.detach()
             b2 = None if gc2.bias is None else gc2.bias.detach()
             _capi.check(lib.ggcn_block_fused(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack1), _capi.ptr(pack12),
-                                             _capi.ptr(csr.graph_ops), _capi.ptr(b1), _capi.ptr(mid), _capi.ptr(b2),
+                                             _capi.ptr(csr.graph_ops), _capi.ptr(csr.graph_ops2(0 if kprec == "bf16x3" else 1)),
+                                             _capi.ptr(b1), _capi.ptr(mid), _capi.ptr(b2),
                                              B, T, K, F, _capi.ptr(gate1), _capi.ptr(gate2), _capi.ptr(gcn1), F,
                                              _capi.ptr(xo), F, _capi.ptr(x1), _capi.ptr(y1), _capi.ptr(out),
                                              _capi.ptr(part), _capi.PREC[kprec], st), "ggcn_block_fused")

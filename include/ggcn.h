@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 9
+#define GGCN_ABI_VERSION 10
 #define GGCN_MASK_MAX_T 256   /* largest graph the row-mask (one-launch) path takes */
 
 typedef void *ggcn_stream_t;
@@ -126,8 +126,17 @@ int ggcn_csr_transpose(const int32_t *rowptr, const int32_t *colidx, const float
  * Built once per adjacency (it replaces, per column tile and wavefront, the expansion of the masks, 32 IEEE
  * divisions and 16 cross-lane moves per graph).  graph_ops: ggcn_graph_operands_bytes(B) bytes, 16-byte aligned. */
 #define GGCN_GRAPH_OPS_BYTES 2176
+/* The block's second layer applies the normalised adjacency twice (bert_amir5.py:626,639 without a non-linearity in between):
+ * ggcn_graph_operands2 folds the two into ONE operand per graph, M2 = (D.A)^2 with D = diag(1 / (rowsum(A) + 1)) (gcn.py:35),
+ * as the A operand of the aggregation MFMA in the launch's plane type (`plane`: 0 = bf16 pairs for GGCN_PREC_BF16X3, 1 = fp16
+ * pairs for GGCN_PREC_F16MX8): hi and lo parts of M2 * 2^10 (the scale keeps the lo part out of fp16's subnormals; the
+ * epilogue multiplies by 2^-10), two k-steps each, plus rowsum(D.A) per row (the factor of the `mid` bias):
+ * GGCN_GRAPH_OPS2_BYTES per graph.  ggcn_block_fused reads it for its W12 column tiles. */
+#define GGCN_GRAPH_OPS2_BYTES 4224
 size_t ggcn_graph_operands_bytes(int B);
 int ggcn_graph_operands(const uint32_t *rowmask, int B, int T, void *graph_ops, ggcn_stream_t stream);
+size_t ggcn_graph_operands2_bytes(int B);
+int ggcn_graph_operands2(const uint32_t *rowmask, int B, int T, int plane, void *graph_ops2, ggcn_stream_t stream);
 
 /* Row masks from an existing batched CSR (T <= GGCN_MASK_MAX_T). */
 int ggcn_csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T,
@@ -288,9 +297,11 @@ int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack,
  * (or NULL), pool_out = max_t x ([B,F] or NULL), gcn1 [N, ld1] only when non-NULL (nothing downstream
  * of the block reads it), overlap_partial (NULL or float[B*ceil(F/64)]) as in ggcn_layer_fused -- finish
  * it with ggcn_overlap_reduce.  Same flop count as two ggcn_layer_fused launches; X is read once and the
- * 4.N.F-byte write + read of gcn1 disappears.  Training keeps the two-launch path (autograd needs gcn1). */
+ * 4.N.F-byte write + read of gcn1 disappears.  Training keeps the two-launch path (autograd needs gcn1).
+ * graph_ops: ggcn_graph_operands blocks (layer 1's aggregation); graph_ops2: ggcn_graph_operands2 blocks in the plane type
+ * of `precision` (layer 2: both aggregations as one application of (D.A)^2, the `mid` bias times rowsum(D.A)). */
 int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12,
-                     const void *graph_ops, const float *bias1, const float *bias_mid, const float *bias2,
+                     const void *graph_ops, const void *graph_ops2, const float *bias1, const float *bias_mid, const float *bias2,
                      int B, int T, int K, int F, const float *gate1, const float *gate2,
                      float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
                      float *x1, float *y1, float *pool_out, float *overlap_partial,

@@ -1141,6 +1141,42 @@ def test_zero_gates_pool_to_signed_zero_not_minus_inf(pkg, dev, precision, fused
 
 
 # ---------------------------------------------------------------- the block as ONE launch (ggcn_block_fused)
+@pytest.mark.parametrize("plane", [0, 1], ids=["bf16-pairs", "fp16-pairs"])
+def test_folded_second_layer_operand_matches_numpy(pkg, dev, plane):
+    """ggcn_graph_operands2: the block's second layer applies D.A twice (bert_amir5.py:626,639; gcn.py:35,41); the launch
+    applies the precomputed (D.A)^2 instead.  The device blocks -- hi + lo fragments of (D.A)^2 * 2^10 in MFMA operand order,
+    rowsum(D.A) in accumulator order -- decoded on the host against numpy's float64 (D.A) @ (D.A), ragged graphs included."""
+    from ed_gated_gcn_amd import synth
+    B, T = 11, 29
+    lens = np.random.default_rng(3).integers(1, T + 1, size=B)
+    adj = synth.dependency_batch(B, T, 4.0, seed=9, lengths=lens)
+    csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj).to(dev))
+    raw = csr.graph_ops2(plane).cpu().numpy().reshape(B, 4224)
+    a = adj.astype(np.float64)
+    da = a / (a.sum(-1, keepdims=True) + 1.0)
+    want = da @ da
+    def decode16(u16):
+        if plane == 1:
+            return u16.view(np.float16).astype(np.float64)
+        return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    got = np.zeros((B, 32, 32))
+    for s_ in range(2):
+        hi = decode16(raw[:, s_ * 1024:(s_ + 1) * 1024].copy().view(np.uint16).reshape(B, 64, 8))
+        lo = decode16(raw[:, 2048 + s_ * 1024:2048 + (s_ + 1) * 1024].copy().view(np.uint16).reshape(B, 64, 8))
+        for lane in range(64):
+            r, h = lane & 31, lane >> 5
+            for e in range(8):
+                got[:, r, 16 * s_ + 8 * (e >> 2) + 4 * h + (e & 3)] = (hi[:, lane, e] + lo[:, lane, e]) / 1024.0
+    assert np.abs(got[:, :T, :T] - want).max() <= (2.0 ** -16 if plane == 0 else 2.0 ** -20)
+    assert np.abs(got[:, T:, :]).max() == 0 and np.abs(got[:, :, T:]).max() == 0          # the 32-row slot beyond T: zeros
+    rho = raw[:, 4096:4224].copy().view(np.float32).reshape(B, 2, 16)
+    for hh in range(2):
+        for rr in range(16):
+            row = (rr & 3) + 8 * (rr >> 2) + 4 * hh
+            if row < T:
+                np.testing.assert_allclose(rho[:, hh, rr], da.sum(-1)[:, row], rtol=1e-6)
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
 @pytest.mark.parametrize("B,T,H,bias", [(64, 32, 768, True), (33, 31, 256, True), (6, 7, 96, False), (130, 32, 300, True)])
 def test_one_launch_block_equals_two_launches(pkg, dev, B, T, H, bias, precision):

@@ -74,10 +74,13 @@ def time_variants(what, names):
         lib = ctypes.CDLL(path)
         lib.ggcn_abi_version.restype = ctypes.c_int
         new_abi = lib.ggcn_abi_version() >= 7      # 7: graph_ops argument (ggcn_graph_operands blocks)
+        lib._abi = lib.ggcn_abi_version()
         for fn, (res, args) in _capi.PROTOTYPES.items():
             if hasattr(lib, fn):
                 if fn == "ggcn_layer_fused" and not new_abi:
                     args = args[:4] + args[5:]
+                if fn == "ggcn_block_fused" and lib._abi < 10:   # before ABI 10: no graph_ops2 argument
+                    args = args[:5] + args[6:]
                 getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
         lib._new_abi = new_abi
         prec = 4 if n.endswith("@mx6") else 2 if n.endswith("@mx8") else 0
@@ -115,8 +118,12 @@ def time_variants(what, names):
             rc = rc or lib.ggcn_layer_fused(p(out), H, p(pack), *masks, p(b), B, T, H, H, p(g2), p(g2), None,
                                             p(y), H, p(pa), None, None, None, None, prec, st)
         elif what == "blockfused":    # the whole gated block as one launch (timing: W12 := the same image)
-            rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack), gops, p(b), p(b), p(b), B, T, H, H, p(g1), p(g2),
-                                      None, H, p(out), H, p(pa), p(pb), p(pc), p(part), prec, st)
+            if lib._abi >= 10:   # ABI 10: the block's second layer reads ggcn_graph_operands2 blocks
+                rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack), gops, p(csr.graph_ops2(0 if prec == 0 else 1)), p(b), p(b), p(b), B, T, H, H,
+                                          p(g1), p(g2), None, H, p(out), H, p(pa), p(pb), p(pc), p(part), prec, st)
+            else:
+                rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack), gops, p(b), p(b), p(b), B, T, H, H, p(g1), p(g2),
+                                          None, H, p(out), H, p(pa), p(pb), p(pc), p(part), prec, st)
         elif what == "fused":
             rc = lib.ggcn_layer_fused(p(x), H, p(pack), *masks, p(b), B, T, H, H, None, p(g1), p(g2),
                                       p(out), H, p(pa), p(pb), None, None, None, prec, st)
