@@ -42,14 +42,37 @@ constexpr int kDmaLds = kTile + 2 * kDmaB;  // 160 KiB: everything a CU has
 constexpr int kIdxCapL = 4096;              // staged column ids per graph (more: read from global memory)
 // after the main loop, where the W buffers were:
 constexpr int kOffRp = kTile + LC * 2;                          // (row LR of the tile: all zeros) int[LR + 1]
-constexpr int kOffCol = kOffRp + ((LR + 1) * 4 + 15) / 16 * 16; // unsigned short[kIdxCapL + 8] (8 spare ids: the 8-wide reads overrun a row)
-constexpr int kOffRed = kOffCol + (kIdxCapL + 8) * 2;           // float[2][16][LC]
-static_assert(kOffRed + 2 * 16 * LC * 4 <= kDmaLds, "the epilogue's LDS map must fit where the W buffers were");
+constexpr int kColSpare = 48;                                   // codes behind the last staged one: reads overrun a row (8) / gather one k-step past a row block (32)
+constexpr int kOffCol = kOffRp + ((LR + 1) * 4 + 15) / 16 * 16; // unsigned short[kIdxCapL + kColSpare]: ROW CODES (below)
+constexpr int kOffRed = kOffCol + (kIdxCapL + kColSpare) * 2;   // float[2][16][LC]
+constexpr int kOffInv = kOffRed + 2 * 16 * LC * 4;              // float[LR]: 1 / (degree + 1) per row (the MFMA form of the neighbour sums)
+constexpr int kOffLut = (kOffInv + LR * 4 + 127) / 128 * 128;   // uint2[16]: 4 mask bits -> 4 fp16 (1.0 / 0.0), the selection fragments of the MFMA sums (128-aligned: the entry offset is ORed in)
+static_assert(kOffLut + 16 * 8 <= kDmaLds, "the epilogue's LDS map must fit where the W buffers were");
+// A staged column id is kept as the ROW CODE (id << 2) | class: code << 6 is the byte address of the row's 64-byte unit
+// `class` in the hidden tile.  class = id & 3 when the tile is stored unit-swizzled (MFMA neighbour sums: unit u of row r lies
+// at unit u ^ (r & 3)), 0 when it is stored plain (lane sums).  Slots past the graph's last edge hold the all-zero row LR.
+constexpr int kCodeZero = LR << 2;
 
 #define GGCN_SB() __builtin_amdgcn_sched_barrier(0)
+// timing-only switches of the MFMA neighbour sums (lab builds; wrong results): 1 no MFMAs, 2 no transposed reads, 4 no row
+// stores, 8 no selection fragments, 16 no normalise / pools / stores at all
+#ifndef GGCN_LAB_LONG
+#define GGCN_LAB_LONG 0
+#endif
+#ifndef GGCN_LAB_LONG_AUX
+#define GGCN_LAB_LONG_AUX 2     // cache policy of the row stores (buffer intrinsic aux: 1 sc0, 2 nt, 16 sc1)
+#endif
+#ifndef GGCN_LAB_LONG_XAUX
+#define GGCN_LAB_LONG_XAUX 0    // ... of the X pieces' LDS-DMA loads
+#endif
+#ifndef GGCN_LAB_LONG_WAUX
+#define GGCN_LAB_LONG_WAUX 0    // ... of the W pieces' LDS-DMA loads
+#endif
 
-// hidden tile: row r at r * 256 B (LC * 2), plain: the reads of the neighbour-sum phase are conflict-free by the ORDER in
-// which a lane takes its two chunks (see there); an XOR keyed on the row would break exactly that.
+// hidden tile: row r at r * 256 B (LC * 2).  Lane sums (weighted edges, > kIdxCapL edges): plain -- their reads are
+// conflict-free by the ORDER in which a lane takes its two chunks (see there); an XOR keyed on the row would break exactly
+// that.  MFMA sums: the 64-byte unit (32 columns = one MFMA column block) XORed with row & 3 -- a transposed read takes the
+// same unit of FOUR source rows per 32-lane half, and plain rows would all sit on the same 16 banks (4-way).
 
 // acc[0..7] += w * (the 8 halves of v)   (v_fma_mix_f32: the fp16 operand is read from its half of the dword)
 __device__ __forceinline__ void fma_half8l(const uint4 &v, float w, float (&acc)[8])
@@ -81,6 +104,7 @@ struct LongArgs {
     __half *out; int64_t ldo;
     float *pool_a, *pool_b;
     int B, T, K, F, n_ct, records;
+    int lane_sums;   // 1: neighbour sums by lanes for every graph (GGCN_LONG_LANE_SUMS=1: the round-3 form, for A/B timing)
 };
 
 template <bool HAS_VALS, bool FULLT>
@@ -112,6 +136,9 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
     // the W buffers occupy the CSR's place during the main loop: the CSR waits in registers (unconditional loads from
     // clamped indices: a branch per load would serialise eight memory latencies)
     int rp_reg = a.rowptr[node0 + (tid < T ? tid : 0)] - e_base;
+    const int rp_next = a.rowptr[node0 + (tid < T ? tid + 1 : 1)] - e_base;
+    // neighbour sums on the MFMAs (unweighted edges, ids staged in LDS) or by lanes: workgroup-uniform
+    const bool mma = !HAS_VALS && staged && !a.lane_sums;
     unsigned short col_reg[kIdxCapL / LTHR];
     {
         const int32_t *cbase = nnz_g > 0 ? a.colidx + e_base : a.rowptr + node0;
@@ -149,12 +176,12 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
             st = st < stages ? st : stages - 1;
             if (t < 8) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc[t] + st * LBK),
-                                                 (__attribute__((address_space(3))) void *)(lds + buf * kDmaA + (64 * t + 8 * wave) * 128), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(lds + buf * kDmaA + (64 * t + 8 * wave) * 128), 16, 0, GGCN_LAB_LONG_XAUX);
             } else {
                 int rec = 2 * st + (wave & 1);
                 rec = rec < a.records ? rec : a.records - 1;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + (int64_t)rec * mx8::STAGE_PACK_BYTES + (t - 8) * 1024),
-                                                 (__attribute__((address_space(3))) void *)(lds + bdst + buf * kDmaB + (t - 8) * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(lds + bdst + buf * kDmaB + (t - 8) * 1024), 16, 0, GGCN_LAB_LONG_WAUX);
             }
         };
         const int sw = ((lane & 31) >> 1) & 7;
@@ -207,9 +234,18 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
         // the CSR out of its registers into the W buffers' place (every DMA has landed: the stage's closing barrier)
         if (tid < T) s_rp[tid] = rp_reg;
         if (tid == 0) s_rp[T] = nnz_g;
+        reinterpret_cast<float *>(lds + kOffInv)[tid] = tid < T ? 1.0f / ((float)(rp_next - rp_reg) + 1.0f) : 1.0f;   // gcn.py:35
         if (staged) {
+            const int cls = mma ? 3 : 0;
 #pragma unroll
-            for (int j = 0; j < kIdxCapL / LTHR; ++j) s_col[tid + LTHR * j] = col_reg[j];
+            for (int j = 0; j < kIdxCapL / LTHR; ++j) {
+                const int idx = tid + LTHR * j, id = col_reg[j];
+                s_col[idx] = (unsigned short)(idx < nnz_g ? (id << 2) | (id & cls) : kCodeZero);
+            }
+            if (tid < kColSpare) s_col[kIdxCapL + tid] = (unsigned short)kCodeZero;
+            if (tid < 16)
+                *reinterpret_cast<uint2 *>(lds + kOffLut + 8 * tid) =
+                    make_uint2(((tid & 1) ? 0x3C00u : 0u) | ((tid & 2) ? 0x3C000000u : 0u), ((tid & 4) ? 0x3C00u : 0u) | ((tid & 8) ? 0x3C000000u : 0u));
         }
     }
     GGCN_LT(1);
@@ -220,19 +256,23 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
     {
         const int c = lane & 31, h = lane >> 5;
         const bool odd = lane & 1;
+        // unit swizzle (MFMA sums): the rows of this lane have row & 3 = (odd + (r & 3)) & 3, r even
+        const int x0 = mma ? (odd ? 1 : 0) << 6 : 0, x2 = mma ? (odd ? 3 : 2) << 6 : 0;
+        const unsigned selp2 = odd ? 0x03020706u : 0x05040100u;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < RN; ++j) {
-                char *base = lds + (128 * rg + 32 * i + 4 * h + (odd ? 1 : 0)) * (LC * 2) + 2 * (64 * cg + 32 * j + (c & ~1));
+                const int boff = (128 * rg + 32 * i + 4 * h + (odd ? 1 : 0)) * (LC * 2) + 2 * (64 * cg + 32 * j + (c & ~1));
+                char *base0 = lds + (boff ^ x0), *base2 = lds + (boff ^ x2);
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float mine0 = acc[i][j][r], mine1 = acc[i][j][r + 1];
-                    const float send = odd ? mine0 : mine1;
-                    const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-                    const float lo = odd ? recv : mine0, hi = odd ? mine1 : recv;
-                    const __half2 v = __floats2half2_rn(lo, hi);
-                    *reinterpret_cast<__half2 *>(base + (8 * (r >> 2) + (r & 3)) * (LC * 2)) = v;
+                    // round first, (row r, row r + 1) of the own column in one register; then one DPP move and one byte
+                    // permute with a per-lane selector: even lanes (mine.lo, partner.lo), odd lanes (partner.hi, mine.hi)
+                    const unsigned mu = __builtin_bit_cast(unsigned, __floats2half2_rn(acc[i][j][r], acc[i][j][r + 1]));
+                    const unsigned pu = (unsigned)__builtin_amdgcn_mov_dpp((int)mu, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                    *reinterpret_cast<unsigned *>(((r & 3) ? base2 : base0) + (8 * (r >> 2) + (r & 3)) * (LC * 2)) =
+                        __builtin_amdgcn_perm(pu, mu, selp2);
                 }
             }
     }
@@ -256,10 +296,17 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
         live[h] = col0 < F;                 // F % 8 == 0 (launcher)
 #pragma unroll
         for (int k = 0; k < 8; ++k) { vb[h][k] = 0.0f; vsg[h][k] = 1.0f; vmax[h][k] = -INFINITY; vmin[h][k] = INFINITY; }
-        if (live[h]) {
+        if (live[h] && !mma) {
             if (a.bias) ld8(a.bias + col0, vb[h]);
             if (a.store_gate) ld8(a.store_gate + (int64_t)b * F + col0, vsg[h]);
         }
+    }
+    // the pools' gates of this thread's column (used after the last barrier: asked for now, so that their latency is not the tail)
+    float pga = 1.0f, pgb = 1.0f;
+    if (tid < LC && ct * LC + tid < F) {
+        const int64_t g = (int64_t)b * F + ct * LC + tid;
+        if (a.pool_a && a.pool_gate_a) pga = a.pool_gate_a[g];
+        if (a.pool_b && a.pool_gate_b) pgb = a.pool_gate_b[g];
     }
     const int32_t *cgp = a.colidx + e_base;
     const float *vg = HAS_VALS ? a.vals + e_base : nullptr;
@@ -297,7 +344,7 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
                     uint4 t[8][2];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int base = rem > j ? (c[j] << 8) : (LR << 8);
+                        const int base = (rem > j ? c[j] : kCodeZero) << 6;    // row codes of class 0 here (plain tile)
                         t[j][0] = *reinterpret_cast<const uint4 *>(lds + base + o0);
                         t[j][1] = *reinterpret_cast<const uint4 *>(lds + base + o1);
                     }
@@ -330,12 +377,187 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
                     union { uint4 u; __half2 hh[4]; } o;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o.hh[k] = __floats2half2_rn(v[2 * k] * vsg[h][2 * k], v[2 * k + 1] * vsg[h][2 * k + 1]);
-                    *reinterpret_cast<uint4 *>(a.out + (node0 + r) * a.ldo + ct * LC + 8 * ch[h]) = o.u;
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o.u), reinterpret_cast<u32x4 *>(a.out + (node0 + r) * a.ldo + ct * LC + 8 * ch[h]));
                 }
             }
         }
     };
-    if (staged) rows(std::true_type{});
+    // ---- 3'. the same sums on the MFMAs (unweighted edges, ids staged): out[32 rows][128 columns] = S . H, where the k
+    // axis runs over the EDGE SLOTS of the row block (CSR order: the slots of row m are [rp[m], rp[m + 1])), S[m][k] = 1 if
+    // slot k belongs to row m -- built in registers from the two row pointers of the lane, no memory -- and H[k][.] is the
+    // source row of slot k, gathered AND transposed by ds_read_b64_tr_b16: lane 4 q + p of a 16-lane group supplies the
+    // address of source row q (its own row code), every lane receives 4 k-values of its own column.  16 slots per MFMA
+    // step, 4 column blocks per step; slots past the block's last edge belong to later rows (S = 0, finite H) or hold the
+    // zero row.  fp32 accumulation of exact products (1.0 x fp16): the sum differs from the lane form only in the order
+    // of its fp32 additions.
+    auto rows_mma = [&]() {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const int m = lane & 31, kg = lane >> 5, qs = (lane & 15) >> 2;
+        const int lanepart = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+        const bool odd = lane & 1;
+        const float *s_inv = reinterpret_cast<const float *>(lds + kOffInv);
+        const int nrb = (T + 31) >> 5;
+        float bj[4], gj[4], pmx[4], pmn[4];
+        int lane_off[4];
+        const int64_t ldo = a.ldo;
+        const int cols_here = F - ct * LC < LC ? F - ct * LC : LC;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = ct * LC + 32 * j + m;
+            const bool live_c = col < F;
+            bj[j] = (a.bias && live_c) ? a.bias[col] : 0.0f;
+            gj[j] = (a.store_gate && live_c) ? a.store_gate[(int64_t)b * F + col] : 1.0f;
+            pmx[j] = -INFINITY; pmn[j] = INFINITY;
+            // even lanes store (row, columns m, m + 1), odd lanes (row + 1, columns m - 1, m); dead columns: past the buffer
+            lane_off[j] = live_c ? (int)(((4 * kg + (odd ? 1 : 0)) * ldo + 32 * j + (m & ~1)) * 2) : 0x40000000;
+        }
+        __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+            a.out ? (void *)(a.out + node0 * ldo + ct * LC) : (void *)a.rowptr, 0,
+            a.out ? (int)((((int64_t)T - 1) * ldo + cols_here) * 2) : 0, 0x00020000);   // rows >= T and an absent `out`: out of range, dropped
+        const unsigned selp = odd ? 0x03020706u : 0x05040100u;   // v_perm_b32(partner, mine): even (mine.lo, partner.lo), odd (partner.hi, mine.hi)
+        const unsigned short *codes = s_col + 8 * kg + qs;
+        unsigned lutbase = kOffLut;
+        asm volatile("" : "+v"(lutbase));    // (kept in a register: an address too large for the ds offset field, ORed into the entry offset)
+        for (int rb = wave; rb < nrb; rb += 8) {
+            const int R0 = 32 * rb;
+            const int r_lo = R0 + m < T ? R0 + m : T, r_hi = R0 + m + 1 < T ? R0 + m + 1 : T;
+            const int lo = s_rp[r_lo], hi = s_rp[r_hi];
+            const int sb = __builtin_amdgcn_readlane(lo, 0), se = __builtin_amdgcn_readlane(hi, 31);
+            const int nks = (se - sb + 15) >> 4;
+            f32x16 sum[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum[j][r] = 0.0f;
+            // slots of this lane in k-step ks: sb + 16 ks + 8 kg + 0..7
+            const unsigned short *cp = codes + sb;
+            typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef __attribute__((address_space(3))) const u32x2 *lds_u2;
+            // S[m][8 kg + i], i = 0..7: 1.0 where lo <= slot < hi -- the 8 mask bits from the lane's two row pointers, the
+            // fp16 fragments of their two nibbles from a 16-entry table in LDS (128 B = 32 banks: no conflicts)
+            int rl = lo - sb - 8 * kg, rh = hi - sb - 8 * kg;     // the row's slot range relative to this lane's first slot of step 0
+            unsigned ga[2][4];
+            auto addresses = [&](int c0, int c1) {
+                ga[0][0] = (unsigned)c0 << 6 | lanepart; ga[1][0] = (unsigned)c1 << 6 | lanepart;   // (the tile starts at LDS byte 0)
+#pragma unroll
+                for (int j = 1; j < 4; ++j) { ga[0][j] = ga[0][0] ^ (j << 6); ga[1][j] = ga[1][0] ^ (j << 6); }
+            };
+            auto gather = [&](f16x8 (&bf)[4]) {
+                if ((GGCN_LAB_LONG) & 2) return;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    union { f16x8 v; s16x4 h[2]; } u;
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)ga[0][j]);
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)ga[1][j]);
+                    bf[j] = u.v;
+                }
+            };
+            auto select = [&](f16x8 &sel) {
+                if ((GGCN_LAB_LONG) & 8) return;
+                const int clo = min(max(rl, 0), 8), chi = min(max(rh, clo), 8);
+                unsigned mask;
+                asm("v_bfm_b32 %0, %1, %2" : "=v"(mask) : "v"(chi - clo), "v"(clo));     // ((1 << width) - 1) << offset
+                rl -= 16; rh -= 16;
+                union { f16x8 v; u32x2 d[2]; } u;
+                u.d[0] = *(lds_u2)(size_t)(((mask << 3) & 0x78u) | lutbase);
+                u.d[1] = *(lds_u2)(size_t)(((mask >> 1) & 0x78u) | lutbase);
+                sel = u.v;
+            };
+            // One step (source order = issue order): between the 4 MFMAs of step k leave, unconditionally, the 8 transposed
+            // reads of step k + 1 (addresses ready since step k - 1), its selection fragment, the addresses of step k + 2
+            // and the codes of step k + 3 -- every LDS result has at least two MFMAs and their companions between issue
+            // and use.  (A branch around them would make the compiler wait for them before this step's MFMAs; past the
+            // block they touch rows of later slots or the zero row -- finite, unused.)
+            f16x8 bf[2][4], sel[2];
+            addresses(cp[0], cp[4]);
+            gather(bf[0]);
+            select(sel[0]);
+            addresses(cp[16], cp[20]);
+            int n0 = cp[32], n1 = cp[36];
+            auto step = [&](int k, auto cur_c) {
+                constexpr int cur = decltype(cur_c)::value;
+                GGCN_SB();
+                if (!((GGCN_LAB_LONG) & 1)) sum[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sel[cur], bf[cur][0], sum[0], 0, 0, 0);
+                GGCN_SB();
+                gather(bf[cur ^ 1]);
+                GGCN_SB();
+                if (!((GGCN_LAB_LONG) & 1)) sum[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sel[cur], bf[cur][1], sum[1], 0, 0, 0);
+                GGCN_SB();
+                select(sel[cur ^ 1]);
+                GGCN_SB();
+                if (!((GGCN_LAB_LONG) & 1)) sum[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sel[cur], bf[cur][2], sum[2], 0, 0, 0);
+                GGCN_SB();
+                addresses(n0, n1);
+                n0 = cp[16 * (k + 3)]; n1 = cp[16 * (k + 3) + 4];
+                GGCN_SB();
+                if (!((GGCN_LAB_LONG) & 1)) sum[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sel[cur], bf[cur][3], sum[3], 0, 0, 0);
+                GGCN_SB();
+            };
+            int ks = 0;
+            for (; ks + 1 < nks; ks += 2) {
+                step(ks, std::integral_constant<int, 0>{});
+                step(ks + 1, std::integral_constant<int, 1>{});
+            }
+            if (ks < nks) step(ks, std::integral_constant<int, 0>{});
+            // normalise, bias, pools, gate, fp16 rows: lane (m, kg) holds column m of rows R0 + 4 kg + 8 (r >> 2) + (r & 3)
+            float inv[16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(s_inv + R0 + 4 * kg + 8 * t);
+                inv[4 * t] = q4.x; inv[4 * t + 1] = q4.y; inv[4 * t + 2] = q4.z; inv[4 * t + 3] = q4.w;
+            }
+            const int s_row = (int)(R0 * ldo * 2);
+            // (straight-line instantiations: whole row block or one that straddles T, with or without the row stores)
+            auto finish = [&](auto whole_c, auto out_c) {
+                constexpr bool WHOLE = decltype(whole_c)::value, OUT = decltype(out_c)::value;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float v0 = fmaf(sum[j][r], inv[r], bj[j]), v1 = fmaf(sum[j][r + 1], inv[r + 1], bj[j]);   // gcn.py:41,43
+                        if constexpr (WHOLE) {
+                            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(pmx[j]) : "v"(v0), "v"(v1));
+                            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(pmn[j]) : "v"(v0), "v"(v1));
+                        } else {
+                            const int row = R0 + 4 * kg + 8 * (r >> 2) + (r & 3);
+                            const float a0 = row < T ? v0 : -INFINITY, a1 = row + 1 < T ? v1 : -INFINITY;
+                            const float i0 = row < T ? v0 : INFINITY, i1 = row + 1 < T ? v1 : INFINITY;
+                            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(pmx[j]) : "v"(a0), "v"(a1));
+                            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(pmn[j]) : "v"(i0), "v"(i1));
+                        }
+                        if constexpr (OUT && !((GGCN_LAB_LONG) & 4)) {
+                            const __half2 mine = __floats2half2_rn(v0 * gj[j], v1 * gj[j]);     // (row r, row r + 1) of column m
+                            const unsigned mu = __builtin_bit_cast(unsigned, mine);
+                            const unsigned pu = (unsigned)__builtin_amdgcn_mov_dpp((int)mu, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                            const unsigned o = __builtin_amdgcn_perm(pu, mu, selp);
+                            __builtin_amdgcn_raw_buffer_store_b32(o, orsrc, lane_off[j], s_row + (int)((8 * (r >> 2) + (r & 3)) * ldo * 2), GGCN_LAB_LONG_AUX);
+                        }
+                    }
+            };
+            const bool whole = R0 + 32 <= T;        // wavefront-uniform
+            if ((GGCN_LAB_LONG) & 16) { pmx[0] = fmaxf(pmx[0], sum[0][0] + sum[1][0] + sum[2][0] + sum[3][0]); continue; }
+            if (whole) { if (a.out) finish(std::true_type{}, std::true_type{}); else finish(std::true_type{}, std::false_type{}); }
+            else { if (a.out) finish(std::false_type{}, std::true_type{}); else finish(std::false_type{}, std::false_type{}); }
+        }
+        // the two lane halves hold different rows of the same columns
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pmx[j] = fmaxf(pmx[j], __shfl_xor(pmx[j], 32));
+            pmn[j] = fminf(pmn[j], __shfl_xor(pmn[j], 32));
+        }
+        if ((a.pool_a || a.pool_b) && lane < 32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {                                       // (slots 0..7: the reduction below reads 8 in this form)
+                s_red[(0 * 16 + wave) * LC + 32 * j + m] = pmx[j];
+                s_red[(1 * 16 + wave) * LC + 32 * j + m] = pmn[j];
+            }
+        }
+    };
+    if (mma) rows_mma();
+    else if (staged) rows(std::true_type{});
     else rows(std::false_type{});
     GGCN_LT(3);
     GGCN_LT_WAVE7(7);
@@ -343,6 +565,7 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
     if (a.pool_a || a.pool_b) {
         // max / min over the 8 row groups of the wavefront (lanes l, l ^ 8, l ^ 16, l ^ 32 hold the same chunk pair only
         // when their parity agrees: xor 16 and 32 keep it; xor 8 flips it and swaps the two chunks)
+        if (!mma) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -352,8 +575,9 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
                 vmin[h][k] = fminf(vmin[h][k], __shfl_xor(vmin[h][k], 16));
                 vmin[h][k] = fminf(vmin[h][k], __shfl_xor(vmin[h][k], 32));
             }
+        }
         // s_red[0 = max / 1 = min][slot = 2 wave + par][column]: 16 partial rows per kind
-        if (q8 < 2) {
+        if (!mma && q8 < 2) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -368,13 +592,20 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
         if (tid < LC && ct * LC + tid < F) {
             float mx = s_red[tid], mn = s_red[16 * LC + tid];
 #pragma unroll
-            for (int w = 1; w < 16; ++w) {
+            for (int w = 1; w < 8; ++w) {
                 mx = fmaxf(mx, s_red[w * LC + tid]);
                 mn = fminf(mn, s_red[(16 + w) * LC + tid]);
             }
+            if (!mma) {
+#pragma unroll
+                for (int w = 8; w < 16; ++w) {
+                    mx = fmaxf(mx, s_red[w * LC + tid]);
+                    mn = fminf(mn, s_red[(16 + w) * LC + tid]);
+                }
+            }
             const int64_t g = (int64_t)b * F + ct * LC + tid;
-            if (a.pool_a) { const float ga = a.pool_gate_a ? a.pool_gate_a[g] : 1.0f; a.pool_a[g] = ga * (ga >= 0.0f ? mx : mn); }
-            if (a.pool_b) { const float gb = a.pool_gate_b ? a.pool_gate_b[g] : 1.0f; a.pool_b[g] = gb * (gb >= 0.0f ? mx : mn); }
+            if (a.pool_a) a.pool_a[g] = pga * (pga >= 0.0f ? mx : mn);
+            if (a.pool_b) a.pool_b[g] = pgb * (pgb >= 0.0f ? mx : mn);
         }
     }
     GGCN_LT(4);
@@ -413,6 +644,8 @@ int layer_fused_h(const void *X, int64_t ldx, const void *wpack, const int32_t *
     a.B = B; a.T = T; a.K = K; a.F = F;
     a.n_ct = (F + LC - 1) / LC;
     a.records = K / BK;
+    const char *env = getenv("GGCN_LONG_LANE_SUMS");      // read per call: tests compare the two forms in one process
+    a.lane_sums = (env && env[0] == '1') || (int64_t)T * ldo * 2 >= (int64_t)1 << 30;   // (the MFMA form addresses `out` with 32-bit offsets per graph)
     const int64_t grid = ((int64_t)B + 7) / 8 * 8 * a.n_ct;
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: batch too large", who);
     const bool fullt = T == LR;

@@ -863,9 +863,66 @@ def test_fp16_long_graphs_one_launch(pkg, dev, B, T, K, F, degree, weighted):
     assert torch.equal(pa3, pa) and torch.equal(pb3, pb)
 
 
+def test_long_graph_mfma_sums_edge_structures(pkg, dev):
+    """The MFMA form of the long-graph neighbour sums walks the EDGE SLOTS of a 32-row block 16 at a time, builds the
+    selection matrix from row pointers alone and gathers source rows by transposed LDS reads: the structures that stress
+    that -- a hub row whose edges span many steps, rows without edges, a graph without any edge, a graph with exactly the
+    4096 edges the staging area holds (and one with 4097: lane sums from global ids), a last row block that straddles T, an
+    output width whose last tile has dead columns, a gather whose four rows share one bank class -- against the oracle, the
+    two launches and the lane form; with and without the row output."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(77)
+    B, T, K, F = 6, 333, 128, 200
+    adj = np.zeros((B, T, T), dtype=np.float32)
+    adj[0, 5, :] = 1.0                                   # hub: 333 edges in one row (21 steps)
+    adj[0, 40:60, 7] = 1.0                               # twenty rows with one and the same source
+    adj[0, 200, [4, 8, 12, 16, 20, 24, 28, 32]] = 1.0    # sources of one bank class (row & 3 == 0)
+    # graph 1: no edge at all
+    adj[2] = (rng.random((T, T)) < 0.02).astype(np.float32)
+    adj[2, 100:140, :] = 0.0                             # forty rows without edges (a whole 32-row block among them)
+    for g, want in ((3, 4096), (4, 4097)):               # the staging area's capacity, and one more
+        a = (rng.random((T, T)) < 0.03).astype(np.float32)
+        idx = np.flatnonzero(a.ravel())
+        off = np.flatnonzero(a.ravel() == 0)
+        if len(idx) > want:
+            a.ravel()[rng.choice(idx, len(idx) - want, replace=False)] = 0.0
+        else:
+            a.ravel()[rng.choice(off, want - len(idx), replace=False)] = 1.0
+        assert int(a.sum()) == want
+        adj[g] = a
+    adj[5] = synth.dependency_batch(1, T, 6.0, seed=9).astype(np.float32)[0]
+    x16 = torch.from_numpy(rng.standard_normal((B, T, K)).astype(np.float32)).half()
+    g1 = torch.from_numpy(rng.uniform(-1.0, 1.0, (B, F)).astype(np.float32))
+    g2 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32)))
+    w, b = synth.layer_params(K, F, seed=11)
+    ref = ref_dense.graph_convolution(x16.float(), torch.from_numpy(adj), torch.from_numpy(w), torch.from_numpy(b))
+    one, two = _layer(pkg, dev, w, b, "f16"), _layer(pkg, dev, w, b, "f16", fused=False)
+    xd = x16.to(dev)
+    csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj).to(dev))
+    assert one.takes_long_path(xd, csr)
+    kw = dict(store_gate=g2.to(dev), pool_gate_a=g1.to(dev), pool_gate_b=g2.to(dev), want_pool_a=True, want_pool_b=True)
+    with torch.no_grad():
+        got = one.forward_gated(xd, csr, **kw)
+        ref2 = two.forward_gated(xd, csr, **kw)
+        with _lane_sums():
+            lane = one.forward_gated(xd, csr, **kw)
+        _, pa3, pb3 = one.forward_gated(xd, csr, pool_gate_a=g1.to(dev), pool_gate_b=g2.to(dev), want_out=False,
+                                        want_pool_a=True, want_pool_b=True)
+    scale = max(1.0, float(ref.abs().max()))
+    out, pa, pb = got
+    np.testing.assert_allclose(out.float().cpu().numpy(), (ref * g2[:, None, :]).numpy(), rtol=0, atol=2e-3 * scale + scale * 2.0 ** -11)
+    np.testing.assert_allclose(pa.cpu().numpy(), (ref * g1[:, None, :]).max(dim=1)[0].numpy(), rtol=0, atol=2e-3 * scale)
+    np.testing.assert_allclose(pb.cpu().numpy(), (ref * g2[:, None, :]).max(dim=1)[0].numpy(), rtol=0, atol=2e-3 * scale)
+    for name, u, v in zip(("out", "pool_a", "pool_b"), lane, ref2):
+        assert torch.equal(u, v), "lane sums vs two launches: %s" % name
+    _assert_same_sums(got, ref2, scale, "edge structures")
+    assert torch.equal(pa3, pa) and torch.equal(pb3, pb)
+
+
 def test_config4_full_size_properties(pkg, dev):
     """BASELINE.json configs[3] at full size (256 graphs x 512 tokens, degree 6, hidden 1024, fp16 features) through the
-    one-launch layer: (1) bit-identical to linear + aggregate; (2) graphs are independent -- an 8-graph slice run
+    one-launch layer: (1) the same sums as linear + aggregate (bit-identical with neighbour sums by lanes; with the
+    sums on the MFMAs -- the default for unweighted graphs -- the same exact terms added in fp32 in another order); (2) graphs are independent -- an 8-graph slice run
     alone gives the same numbers; (3) that slice equals the oracle on the fp16-rounded inputs; (4) the pools are the
     max over tokens of gate x what was stored (gate >= 0); (5) doubling the store gate doubles the output exactly."""
     from ed_gated_gcn_amd import synth
@@ -884,7 +941,10 @@ def test_config4_full_size_properties(pkg, dev):
     with torch.no_grad():
         out, pa, pb = one.forward_gated(x, csr, store_gate=g2, pool_gate_a=g1, pool_gate_b=g2, **kw)
         out2, pa2, pb2 = two.forward_gated(x, csr, store_gate=g2, pool_gate_a=g1, pool_gate_b=g2, **kw)
-        assert torch.equal(out, out2) and torch.equal(pa, pa2) and torch.equal(pb, pb2)          # (1)
+        with _lane_sums():
+            outl, pal, pbl = one.forward_gated(x, csr, store_gate=g2, pool_gate_a=g1, pool_gate_b=g2, **kw)
+        assert torch.equal(outl, out2) and torch.equal(pal, pa2) and torch.equal(pbl, pb2)       # (1) lane sums: bit for bit
+        _assert_same_sums((out, pa, pb), (out2, pa2, pb2), max(1.0, float(out2.float().abs().max())), "config 4")   # (1) MFMA sums
         sl = slice(100, 108)
         rps, cis, _ = synth.csr_from_dense_host(adj[sl])
         sub = pkg.BatchedCSR.from_arrays(rps, cis, 8, T, dev)
@@ -909,8 +969,9 @@ def test_config4_full_size_properties(pkg, dev):
 def test_fp16_long_graphs_random_shapes_match_two_launches_bitwise(pkg, dev):
     """The one-launch long-graph layer stages both operands by LDS-DMA behind hand-placed waits: a race would show as
     a rare wrong tile.  40 random shapes (T 129..512, K multiple of 64, F multiple of 8, ragged lengths, weighted or
-    not, B not a multiple of 8), each compared BIT FOR BIT with linear + aggregate of the same arithmetic, the same
-    launch repeated three times."""
+    not, B not a multiple of 8), each compared BIT FOR BIT with linear + aggregate of the same arithmetic (neighbour
+    sums by lanes), the same launch repeated three times; then the default form (sums on the MFMAs where it applies)
+    against the same reference and against itself."""
     from ed_gated_gcn_amd import synth
     rng = np.random.default_rng(2024)
     for case in range(40):
@@ -931,16 +992,51 @@ def test_fp16_long_graphs_random_shapes_match_two_launches_bitwise(pkg, dev):
         csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj).to(dev))
         assert one.takes_long_path(x, csr), (B, T, K, F)
         kw = dict(store_gate=g, pool_gate_a=g, pool_gate_b=g.abs(), want_pool_a=True, want_pool_b=True)
+        what = "case %d (B=%d T=%d K=%d F=%d deg=%.1f weighted=%s)" % (case, B, T, K, F, deg, weighted)
         with torch.no_grad():
             ref = two.forward_gated(x, csr, **kw)
-            for rep in range(3):
+            with _lane_sums():
+                for rep in range(3):
+                    got = one.forward_gated(x, csr, **kw)
+                    for name, u, v in zip(("out", "pool_a", "pool_b"), got, ref):
+                        assert torch.equal(u, v), "%s rep %d, lane sums: %s differs, max %g" % (
+                            what, rep, name, float((u.float() - v.float()).abs().max()))
+            # the default form (MFMA sums for unweighted graphs whose ids fit the staging area): the same terms in another
+            # order against the two launches; launch after launch bit for bit
+            first = one.forward_gated(x, csr, **kw)
+            _assert_same_sums(first, ref, max(1.0, float(ref[0].float().abs().max())), what)
+            for rep in range(2):
                 got = one.forward_gated(x, csr, **kw)
-                for name, u, v in zip(("out", "pool_a", "pool_b"), got, ref):
-                    assert torch.equal(u, v), "case %d rep %d (B=%d T=%d K=%d F=%d deg=%.1f weighted=%s): %s differs, max %g" % (
-                        case, rep, B, T, K, F, deg, weighted, name, float((u.float() - v.float()).abs().max()))
+                for name, u, v in zip(("out", "pool_a", "pool_b"), got, first):
+                    assert torch.equal(u, v), "%s rep %d: %s differs between launches" % (what, rep, name)
 
 
 POISONS = (0x7F800000, 0xFF800000, 0xFFFFFFFF, 0x7C007C00)   # +inf, -inf, NaN / id 65535, fp16 +inf pairs
+
+
+class _lane_sums:
+    """The long-graph layer's neighbour sums by lanes (fp32 additions in CSR order: the arithmetic of ggcn_aggregate_h, bit for
+    bit) instead of on the MFMAs (the same fp32 sums of the same exact terms in the matrix pipe's order).  The library reads
+    the switch on every call."""
+    def __enter__(self):
+        os.environ["GGCN_LONG_LANE_SUMS"] = "1"
+    def __exit__(self, *exc):
+        os.environ.pop("GGCN_LONG_LANE_SUMS", None)
+
+
+def _assert_same_sums(got, ref, scale, what):
+    """One-launch long-graph layer with MFMA neighbour sums against the two launches: identical terms (1.0 x the fp16 hidden
+    values), fp32 accumulation in another order -- the stored fp16 rows may differ by one rounding step where the two fp32
+    sums straddle a rounding boundary, the fp32 pools by a few fp32 ulps of the sum."""
+    out, pa, pb = got
+    out2, pa2, pb2 = ref
+    if out is not None:
+        d = (out.float() - out2.float()).abs()
+        assert bool((d <= 2.0 ** -10 * out2.float().abs() + 2.0 ** -24).all()), "%s: out differs by more than one fp16 step (max %g)" % (what, float(d.max()))
+        assert float((d > 0).float().mean()) < 2e-3, "%s: %.2g of the stored values differ" % (what, float((d > 0).float().mean()))
+    for name, u, v in (("pool_a", pa, pa2), ("pool_b", pb, pb2)):
+        if u is not None:
+            assert float((u - v).abs().max()) <= 2e-6 * scale, "%s: %s differs by %g" % (what, name, float((u - v).abs().max()))
 
 
 def _poison_lds(pkg, dev, pattern):

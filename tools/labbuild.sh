@@ -20,10 +20,13 @@ for f in $CS/build/*.o; do
   for s in "$@"; do [ "$b.hip" == "$s" ] && skip=1; done
   [ $skip == 0 ] && OBJS="$OBJS $f"
 done
+PIDS=""
 for s in "$@"; do
+  rm -f $OUT/obj_$NAME/${s%.hip}.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FLAGS -c $SRC/$s -o $OUT/obj_$NAME/${s%.hip}.o &
+  PIDS="$PIDS $!"
 done
-wait
+for p in $PIDS; do wait $p || { echo "labbuild: a translation unit failed to compile"; exit 1; }; done
 for s in "$@"; do OBJS="$OBJS $OUT/obj_$NAME/${s%.hip}.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libggcn_$NAME.so $OBJS 2>&1 | grep -v hip-link || true
 echo built $NAME
