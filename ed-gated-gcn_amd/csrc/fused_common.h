@@ -72,6 +72,15 @@ __device__ __forceinline__ void store_out4(float *p, const float4 &v)
 #endif
 }
 
+// the same with the non-temporal hint always: the eight-wavefront kernel (129..256-node graphs) re-reads a graph's X rows
+// from L2 once per column tile, and output lines allocated in L2 evict them (512 graphs: 129 nodes 284 -> 264 us, 160: 304 -> 284,
+// 192: 342 -> 331, 231: 412 -> 406; the 32-node and 128-row kernels do not move and keep plain stores)
+__device__ __forceinline__ void store_out4_stream(float *p, const float4 &v)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4 *>(p));
+}
+
 // lanes 0-31 receive the value of lane + 32 (lanes 32-63: unspecified, their own lower-half partner's value)
 __device__ __forceinline__ float upper_half_to_lower(float v)
 {
@@ -522,7 +531,7 @@ __device__ __forceinline__ void epilogue(const FusedArgs &a, const LayerPart &lp
                 const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 64 + (colq ^ (32 * ((row >> 2) & 1)))]);
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 if ((FULLT || row < T) && gcol < F && !((GGCN_LAB_EPI) & 1))   // (GGCN_LAB_EPI 1: timing build without the stores)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), orsrc, voff, 4 * it * ldo * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), orsrc, voff, 4 * it * ldo * 4, (GGCN_LAB_NT_STORE) ? 2 : 0);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                     for (int it = 0; it < 4; ++it) {
                         const int row = 8 * it + (lane >> 3);
                         const float4 v4 = *reinterpret_cast<const float4 *>(&stage_lds[row * 32 + colq]);
-                        if (node0 + row < T && gcol < F) store_out4(tile + row * ldo + colq, v4);
+                        if (node0 + row < T && gcol < F) store_out4_stream(tile + row * ldo + colq, v4);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                 if (out && !((GGCN_LAB_OFF) & 8)) {   // (timing build: no stores)
                     float *dst = out + ((int64_t)g * T + row) * ldo + col0;
                     if constexpr (VST) {
-                        if (cok[j][0]) store_out4(dst, make_float4(o4[0], o4[1], o4[2], o4[3]));
+                        if (cok[j][0]) store_out4_stream(dst, make_float4(o4[0], o4[1], o4[2], o4[3]));
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)

@@ -48,7 +48,7 @@ def time_variants(what, names):
     import ed_gated_gcn_amd as pkg
     from ed_gated_gcn_amd import _capi, synth
     dev = torch.device("cuda:0")
-    B, T, H = int(os.environ.get("LAB_GRAPHS", "4096")), 32, 768
+    B, T, H = int(os.environ.get("LAB_GRAPHS", "4096")), int(os.environ.get("LAB_T", "32")), 768
     N = B * T
     adj = synth.dependency_batch(B, T, 4.0)
     rowptr, colidx, _ = synth.csr_from_dense_host(adj)

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import ed_gated_gcn_amd as pkg
 from ed_gated_gcn_amd import _capi, synth
 lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_lab", "libggcn_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "ltrace")))
+PAD = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # extra halfs per row of X (leading dimension H + PAD)
 for fn, (res, args) in _capi.PROTOTYPES.items():
     getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
 dev = torch.device("cuda:0")
@@ -14,7 +15,8 @@ B, T, H = 256, 512, 1024
 adj = synth.dependency_batch(B, T, 6.0)
 rp, ci, _ = synth.csr_from_dense_host(adj)
 csr = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
-x = torch.randn(B * T, H, device=dev).half()
+xfull = torch.randn(B * T, H + PAD, device=dev).half()
+x = xfull
 w, b = synth.layer_params(H, H, seed=1)
 w, b = torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)
 g1, g2 = torch.rand(B, H, device=dev), torch.rand(B, H, device=dev)
@@ -24,7 +26,7 @@ p = _capi.ptr
 pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H, 3), dtype=torch.uint8, device=dev)
 assert lib.ggcn_weight_pack(p(w), H, H, H, 3, 0, p(pack), None) == 0
 def run():
-    assert lib.ggcn_layer_fused_h(p(x), H, p(pack), p(csr.rowptr), p(csr.colidx), None, p(b), B, T, H, H, p(g2), p(g1), p(g2),
+    assert lib.ggcn_layer_fused_h(p(x), H + PAD, p(pack), p(csr.rowptr), p(csr.colidx), None, p(b), B, T, H, H, p(g2), p(g1), p(g2),
                                   p(out), H, p(pa), p(pb), None) == 0
 for _ in range(300): run()
 torch.cuda.synchronize()
