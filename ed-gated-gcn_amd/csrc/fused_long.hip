@@ -399,7 +399,6 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
         const float *s_inv = reinterpret_cast<const float *>(lds + kOffInv);
         const int nrb = (T + 31) >> 5;
         float bj[4], gj[4], pmx[4], pmn[4];
-        int lane_off[4];
         const int64_t ldo = a.ldo;
         const int cols_here = F - ct * LC < LC ? F - ct * LC : LC;
 #pragma unroll
@@ -409,8 +408,14 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
             bj[j] = (a.bias && live_c) ? a.bias[col] : 0.0f;
             gj[j] = (a.store_gate && live_c) ? a.store_gate[(int64_t)b * F + col] : 1.0f;
             pmx[j] = -INFINITY; pmn[j] = INFINITY;
-            // even lanes store (row, columns m, m + 1), odd lanes (row + 1, columns m - 1, m); dead columns: past the buffer
-            lane_off[j] = live_c ? (int)(((4 * kg + (odd ? 1 : 0)) * ldo + 32 * j + (m & ~1)) * 2) : 0x40000000;
+        }
+        // row stores: even lanes (row, columns c, c + 1), odd lanes (row + 1, columns c - 1, c) of column block 2 jp + (lane >> 5)
+        // (after the blocks' exchange of halves, see finish); dead columns: past the buffer
+        int lane_off2[2];
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            const int cb = 32 * (2 * jp + kg) + (m & ~1);
+            lane_off2[jp] = ct * LC + cb < F ? (int)(((odd ? 1 : 0) * ldo + cb) * 2) : 0x40000000;
         }
         __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
             a.out ? (void *)(a.out + node0 * ldo + ct * LC) : (void *)a.rowptr, 0,
@@ -513,26 +518,39 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
             auto finish = [&](auto whole_c, auto out_c) {
                 constexpr bool WHOLE = decltype(whole_c)::value, OUT = decltype(out_c)::value;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
-                        const float v0 = fmaf(sum[j][r], inv[r], bj[j]), v1 = fmaf(sum[j][r + 1], inv[r + 1], bj[j]);   // gcn.py:41,43
-                        if constexpr (WHOLE) {
-                            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(pmx[j]) : "v"(v0), "v"(v1));
-                            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(pmn[j]) : "v"(v0), "v"(v1));
-                        } else {
-                            const int row = R0 + 4 * kg + 8 * (r >> 2) + (r & 3);
-                            const float a0 = row < T ? v0 : -INFINITY, a1 = row + 1 < T ? v1 : -INFINITY;
-                            const float i0 = row < T ? v0 : INFINITY, i1 = row + 1 < T ? v1 : INFINITY;
-                            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(pmx[j]) : "v"(a0), "v"(a1));
-                            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(pmn[j]) : "v"(i0), "v"(i1));
+                        unsigned o[2];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = 2 * jp + jj;
+                            const float v0 = fmaf(sum[j][r], inv[r], bj[j]), v1 = fmaf(sum[j][r + 1], inv[r + 1], bj[j]);   // gcn.py:41,43
+                            if constexpr (WHOLE) {
+                                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(pmx[j]) : "v"(v0), "v"(v1));
+                                asm("v_min3_f32 %0, %0, %1, %2" : "+v"(pmn[j]) : "v"(v0), "v"(v1));
+                            } else {
+                                const int row = R0 + 4 * kg + 8 * (r >> 2) + (r & 3);
+                                const float a0 = row < T ? v0 : -INFINITY, a1 = row + 1 < T ? v1 : -INFINITY;
+                                const float i0 = row < T ? v0 : INFINITY, i1 = row + 1 < T ? v1 : INFINITY;
+                                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(pmx[j]) : "v"(a0), "v"(a1));
+                                asm("v_min3_f32 %0, %0, %1, %2" : "+v"(pmn[j]) : "v"(i0), "v"(i1));
+                            }
+                            if constexpr (OUT && !((GGCN_LAB_LONG) & 4)) {
+                                const __half2 mine = __floats2half2_rn(v0 * gj[j], v1 * gj[j]);     // (row r, row r + 1) of column m
+                                const unsigned mu = __builtin_bit_cast(unsigned, mine);
+                                const unsigned pu = (unsigned)__builtin_amdgcn_mov_dpp((int)mu, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                                o[jj] = __builtin_amdgcn_perm(pu, mu, selp);
+                            }
                         }
                         if constexpr (OUT && !((GGCN_LAB_LONG) & 4)) {
-                            const __half2 mine = __floats2half2_rn(v0 * gj[j], v1 * gj[j]);     // (row r, row r + 1) of column m
-                            const unsigned mu = __builtin_bit_cast(unsigned, mine);
-                            const unsigned pu = (unsigned)__builtin_amdgcn_mov_dpp((int)mu, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                            const unsigned o = __builtin_amdgcn_perm(pu, mu, selp);
-                            __builtin_amdgcn_raw_buffer_store_b32(o, orsrc, lane_off[j], s_row + (int)((8 * (r >> 2) + (r & 3)) * ldo * 2), GGCN_LAB_LONG_AUX);
+                            // the two column blocks trade halves: afterwards one register holds rows (r, r + 1) of the lower lanes'
+                            // row set for BOTH blocks -- 128 contiguous bytes per row and store instruction, whole lines -- and
+                            // the other the upper lanes' row set (4 rows further)
+                            const auto sw = __builtin_amdgcn_permlane32_swap(o[0], o[1], false, false);
+                            const int so = s_row + (int)((8 * (r >> 2) + (r & 3)) * ldo * 2);
+                            __builtin_amdgcn_raw_buffer_store_b32(sw[0], orsrc, lane_off2[jp], so, GGCN_LAB_LONG_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b32(sw[1], orsrc, lane_off2[jp], so + (int)(4 * ldo * 2), GGCN_LAB_LONG_AUX);
                         }
                     }
             };
