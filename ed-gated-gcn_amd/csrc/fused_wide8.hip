@@ -409,6 +409,12 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
         // The two wavefronts of a column group take the row steps (8 rows each) ALTERNATELY -- step 2 it + rg -- whatever row
         // group their accumulators came from: a 129-node graph is 17 steps, 9 and 8 of them instead of 16 and 1 (the tile in
         // LDS holds every row; the pools meet in LDS anyway).
+        // (two instantiations of the row steps: a full 256-node slot has no padding row and tests every list slot against
+        // the degree; decided per workgroup -- as a run-time flag it cost a compare, a scalar OR and a select per edge)
+        auto row_steps = [&](auto full_c) {
+        constexpr bool FULL_SLOT = decltype(full_c)::value;
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const f32x4v *lds_f4;
         int deg_n = s_deg[8 * rg + q8];
         float inv_n = s_inv[8 * rg + q8];
         uint4 idq_n = *reinterpret_cast<const uint4 *>(s_ids + (8 * rg + q8) * kW8Cap);
@@ -432,8 +438,9 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                 for (int e = 0; e < 8; ++e) {
                     const int base = (int)((idw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
                     int off = tile_lane ^ base;   // (base has no bits below 64; tile_lane = cg base + 16 cl)
-                    if (full_slot) off = e0 + e < deg ? off : zero_lane;   // workgroup-uniform: T = 256
-                    v[e] = *reinterpret_cast<const float4 *>(lds8 + off);
+                    if constexpr (FULL_SLOT) off = e0 + e < deg ? off : zero_lane;
+                    const f32x4v t4 = *(lds_f4)(size_t)off;    // (the dynamic LDS block starts at byte 0)
+                    v[e] = make_float4(t4[0], t4[1], t4[2], t4[3]);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s4[0] += v[e].x; s4[1] += v[e].y; s4[2] += v[e].z; s4[3] += v[e].w; }
@@ -480,6 +487,9 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                 }
             }
         }
+        };   // row_steps
+        if (full_slot) row_steps(std::true_type{});
+        else row_steps(std::false_type{});
     }
     // pools of the graph: max over ALL its rows (bert_amir5.py:635-640): across the 8 row classes of the wavefront (lanes 8
     // apart), then the two row groups meet in LDS
