@@ -179,10 +179,10 @@ template <typename AT>
 struct BufX {
     const AT *base;                       // first row of the workgroup's tile (workgroup-uniform)
     uint32_t bytes;                       // bytes of X from there to the end of the batch (reads beyond return zeros)
-    uint32_t off[Geom<AT>::NP];           // this lane's piece of pass i at stage 0, in bytes from base (padding rows: any valid piece)
+    uint32_t off[Geom<AT>::NP];           // this lane's piece of pass i at stage 0, in bytes from base (padding rows: 2^31, beyond any descriptor)
 };
-// X [total_rows, ldx]; the tile starts at base_row (a real row); rel[i] = this lane's row of pass i relative to it (padding
-// rows: 0).  The launchers admit the buffer path only when 257 rows of ldx elements stay below 2 GiB.
+// X [total_rows, ldx]; the tile starts at base_row (a real row); rel[i] = this lane's row of pass i relative to it, -1 for a
+// padding row (no select per value in the loop: the hardware's range check zeroes it).  The launchers admit the buffer path only when 257 rows of ldx elements stay below 2 GiB.
 template <typename AT>
 __device__ __forceinline__ BufX<AT> make_bufx(const AT *X, int64_t ldx, int64_t base_row, int64_t total_rows,
                                               const int (&rel)[Geom<AT>::NP], int tid)
@@ -192,8 +192,9 @@ __device__ __forceinline__ BufX<AT> make_bufx(const AT *X, int64_t ldx, int64_t 
     b.base = X + base_row * ldx;
     b.bytes = (uint32_t)(left < 0x7fffffff ? left : 0x7fffffff);
 #pragma unroll
-    for (int i = 0; i < Geom<AT>::NP; ++i)
-        b.off[i] = (uint32_t)(((int64_t)rel[i] * ldx + (tid % Geom<AT>::TPR) * Geom<AT>::EPT) * (int64_t)sizeof(AT));
+    for (int i = 0; i < Geom<AT>::NP; ++i)   // rel < 0: a padding row -- an offset no descriptor reaches (bytes <= 2^31 - 1): its loads return zeros
+        b.off[i] = rel[i] < 0 ? 0x80000000u
+                              : (uint32_t)(((int64_t)rel[i] * ldx + (tid % Geom<AT>::TPR) * Geom<AT>::EPT) * (int64_t)sizeof(AT));
     return b;
 }
 // NB (fp32 rows: one staging pass = one 32-row block): only the first NB of this wavefront's four blocks exist at all -- the
@@ -260,7 +261,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
                 if constexpr (!KFULL || ZROWS) {
                     bool in = true;
                     if constexpr (!KFULL) in = gk + 4 * q + c < K;
-                    if constexpr (ZROWS) in = in && avalid[i];
+                    if constexpr (ZROWS && !BUF) in = in && avalid[i];   // (BUF: padding rows lie outside the descriptor and arrive as zeros)
                     x[c] = in ? x[c] : 0.0f;
                 }
             }

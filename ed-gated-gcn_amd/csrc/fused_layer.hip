@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int row = stage_row<float>(i);
-                rel[i] = avalid[i] ? (row >> 5) * T + (row & 31) : 0;   // padding rows read row 0 (zeroed at the split)
+                rel[i] = avalid[i] ? (row >> 5) * T + (row & 31) : -1;   // padding rows: outside the descriptor, zeros
             }
             bx = mx8::make_bufx<float>(a.X, a.ldx, (int64_t)gt0 * T, (int64_t)B * T, rel, tid);   // the tile's first node is always a real one
         }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_f
 #pragma unroll
                 for (int i = 0; i < NP; ++i) {
                     const int row = stage_row<float>(i) + 128 * hh;
-                    rel[i] = avalid[i] ? (row / S) * T + row % S : 0;
+                    rel[i] = avalid[i] ? (row / S) * T + row % S : -1;
                 }
                 bx = mx8::make_bufx<float>(a.X, a.ldx, (int64_t)g0 * T, (int64_t)B * T, rel, tid);
             }

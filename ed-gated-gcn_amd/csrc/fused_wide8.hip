@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
 #pragma unroll
                 for (int i = 0; i < NP; ++i) {
                     const int r = stage_row<float>(i) + 128 * rg;
-                    rel[i] = avalid[i] ? r : 0;
+                    rel[i] = avalid[i] ? r : -1;
                 }
                 bx = mx8::make_bufx<float>(a.X, a.ldx, (int64_t)g * T, (int64_t)B * T, rel, tid & (kThreads - 1));
             }
