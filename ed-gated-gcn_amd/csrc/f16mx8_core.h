@@ -457,16 +457,16 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[0], acc[i][0], 0, 0, 0);
             GGCN_SB();
-            if GGCN_ON(2) { if (i < NP) split_pass(i, k_next1); }
+            if GGCN_ON(2) { if (i < NP && i < GGCN_LAB_XPASSES) split_pass(i, k_next1); }
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[1], acc[i][1], 0, 0, 0);
             GGCN_SB();
-            if GGCN_ON(4) { if (i < NP) write_pass(buf ^ 1, i); }
+            if GGCN_ON(4) { if (i < NP && i < GGCN_LAB_XPASSES) write_pass(buf ^ 1, i); }
             else { _Pragma("unroll") for (int q = 0; q < NQ; ++q) asm volatile("" :: "v"(sp[q].h01), "v"(sp[q].h23), "v"(sp[q].l8), "v"(sp[q].h8)); }
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[0], acc[i][0], 0, 0, 0);
             GGCN_SB();
-            if GGCN_ON(1) { if (i < NP) load_a_pass(i, ka); }
+            if GGCN_ON(1) { if (i < NP && i < GGCN_LAB_XPASSES) load_a_pass(i, ka); }
             else { if (i < NP) { _Pragma("unroll") for (int c = 0; c < EPT; ++c) asm volatile("" : "+v"(ra[i][c])); } }
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[1], acc[i][1], 0, 0, 0);

@@ -31,6 +31,11 @@
 #ifndef GGCN_LAB_OFF
 #define GGCN_LAB_OFF 0
 #endif
+// timing-only: staging passes (X loads, split, plane writes) a thread performs per stage (4 = all; 2 prices a workgroup of
+// eight wavefronts that shares one set of X planes between two column halves; wrong results below 4)
+#ifndef GGCN_LAB_XPASSES
+#define GGCN_LAB_XPASSES 4
+#endif
 
 // f16mx8: 1 = the second column tile's fp16 -> fp8 converts behind the first tile's first MX MFMA
 #ifndef GGCN_LAB_WH8
