@@ -51,6 +51,8 @@ PROTOTYPES = {
                                         c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ggcn_gate_pool_backward_drop": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32,
                                              c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_uint64, c_i32, c_i32, c_i32, c_vp]),
+    "ggcn_gate_pool_backward_agg": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                            c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_uint64, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_layer_fused_drop": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_vp, c_vp, c_i32, ctypes.c_float, ctypes.c_uint64, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_dropout_mask": (c_i32, [c_i64, c_i32, ctypes.c_float, ctypes.c_uint64, c_i32, c_vp, c_vp]),
@@ -69,7 +71,7 @@ PROTOTYPES = {
     "ggcn_gate_overlap": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2, "f16": 3, "f16mx6": 4}
 PACKED = ("bf16x3", "f16mx8", "f16", "f16mx6")  # precisions whose linear reads a ggcn_weight_pack image ("f16": half features only)
 FLAG_WEIGHTED = 1

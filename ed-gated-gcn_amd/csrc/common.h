@@ -87,6 +87,10 @@ int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, c
                        const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                        const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
                        float *d_ga, float *d_gb, float *d_bsum, hipStream_t st, const struct DropSpec *drop = nullptr);
+int gate_pool_backward_agg(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
+                           const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
+                           const float *d_pb, const uint32_t *rowmask, int B, int T, int F, float *dH, int64_t ldh,
+                           float *d_sg, float *d_ga, float *d_gb, float *d_bsum, hipStream_t st, const struct DropSpec *drop = nullptr);
 size_t colsum_workspace_bytes(int F);
 int colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *workspace, hipStream_t st);
 

@@ -168,6 +168,119 @@ __global__ __launch_bounds__(256) void gate_pool_backward_kernel4(
     if (d_gb) { const float v[4] = {dpb[0] * yb[0], dpb[1] * yb[1], dpb[2] * yb[2], dpb[3] * yb[3]}; st4(d_gb + gf, v); }
 }
 
+// The same pass FOLLOWED by the transposed aggregation dH = A^T . D . dY (gcn.py:41 under train.py:120; what
+// ggcn_aggregate_t does in a launch of its own) for graphs of up to 32 nodes with a 0/1 adjacency given as row masks: dY is
+// consumed nowhere else, so it never exists in memory -- a thread (four columns) keeps the 32 x 4 sums of its graph's dH rows in
+// registers and SCATTERS row t of dY, scaled by 1 / (deg_t + 1), into the rows s with A[t][s] = 1.  The row mask is
+// workgroup-uniform: the test of bit s is a scalar compare and branch around four adds, so only real edges cost vector
+// instructions (~5 of 32 per row), and the register index s is a compile-time constant.  Additions per dH row run over t
+// ascending -- ggcn_aggregate_t's order.  HBM: out + d_out read, dH written: the 2 x 4 N F bytes of dY are gone.
+template <bool DROP>
+__global__ __launch_bounds__(256) void gate_pool_backward_agg_kernel(
+    const float *__restrict__ out, int64_t ldo, const float *__restrict__ store_gate,
+    const float *__restrict__ gate_a, const float *__restrict__ gate_b,
+    const float *__restrict__ d_out, int64_t ldd, const float *__restrict__ d_pa,
+    const float *__restrict__ d_pb, const uint32_t *__restrict__ rowmask, int T, int F, int n_slabs,
+    float *__restrict__ dH, int64_t ldh, float *__restrict__ d_sg, float *__restrict__ d_ga, float *__restrict__ d_gb,
+    float *__restrict__ d_bsum, DropSpec drop)
+{
+    const int b = blockIdx.x / n_slabs;
+    const int f = (blockIdx.x - b * n_slabs) * 1024 + 4 * threadIdx.x;
+    if (f >= F) return;
+    const int64_t gf = (int64_t)b * F + f;
+    auto ld4 = [](const float *p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    };
+    float sg[4] = {1.0f, 1.0f, 1.0f, 1.0f}, inv_sg[4] = {1.0f, 1.0f, 1.0f, 1.0f}, ga[4] = {1.0f, 1.0f, 1.0f, 1.0f},
+          gb[4] = {1.0f, 1.0f, 1.0f, 1.0f}, dpa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dpb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (store_gate) {
+        ld4(store_gate + gf, sg);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) inv_sg[c] = sg[c] != 0.0f ? 1.0f / sg[c] : 0.0f;
+    }
+    if (gate_a) ld4(gate_a + gf, ga);
+    if (gate_b) ld4(gate_b + gf, gb);
+    if (d_pa) ld4(d_pa + gf, dpa);
+    if (d_pb) ld4(d_pb + gf, dpb);
+    const float *o = out + (int64_t)b * T * ldo + f;
+    const float *dd = d_out ? d_out + (int64_t)b * T * ldd + f : nullptr;
+
+    float best_a[4], best_b[4], ya[4], yb[4], acc_sg[4];
+    int ia[4], ib[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { best_a[c] = -INFINITY; best_b[c] = -INFINITY; ya[c] = 0.0f; yb[c] = 0.0f; acc_sg[c] = 0.0f; ia[c] = 0; ib[c] = 0; }
+    const uint32_t e0 = DROP ? (uint32_t)((int64_t)b * T * F + f) : 0u;
+#pragma unroll 4
+    for (int t = 0; t < T; ++t) {
+        float o_t[4], d_t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        ld4(o + (int64_t)t * ldo, o_t);
+        if (dd) ld4(dd + (int64_t)t * ldd, d_t);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float ks = 1.0f, ka = 1.0f, kb = 1.0f;
+            if constexpr (DROP) {
+                const uint32_t hh = drop_hash(e0 + (uint32_t)t * (uint32_t)F + (uint32_t)c, drop.seed_lo, drop.seed_hi);
+                ks = drop_keep(hh, drop.sel[0], drop.thr, drop.scale);
+                ka = drop_keep(hh, drop.sel[1], drop.thr, drop.scale);
+                kb = drop_keep(hh, drop.sel[2], drop.thr, drop.scale);
+            }
+            const float y = DROP ? (ks != 0.0f ? o_t[c] * inv_sg[c] / ks : 0.0f) : o_t[c] * inv_sg[c];
+            const float va = y * ga[c] * ka, vb = y * gb[c] * kb;
+            if (va > best_a[c]) { best_a[c] = va; ia[c] = t; ya[c] = y * ka; }
+            if (vb > best_b[c]) { best_b[c] = vb; ib[c] = t; yb[c] = y * kb; }
+            if (dd) acc_sg[c] = fmaf(d_t[c], y * ks, acc_sg[c]);
+        }
+    }
+    float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float acc[32][4];
+#pragma unroll
+    for (int s = 0; s < 32; ++s)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[s][c] = 0.0f;
+    const uint32_t *mrow = rowmask + (int64_t)b * T;   // one word per node (T <= 32)
+    for (int t = 0; t < T; ++t) {
+        float d_t[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gw[4];
+        if (dd) ld4(dd + (int64_t)t * ldd, d_t);
+        const uint32_t m = __builtin_amdgcn_readfirstlane(mrow[t]);                     // (workgroup-uniform)
+        const float w = 1.0f / (float)(__popc(m) + 1);                                    // gcn.py:35
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float ks = 1.0f, ka = 1.0f, kb = 1.0f;
+            if constexpr (DROP) {
+                const uint32_t hh = drop_hash(e0 + (uint32_t)t * (uint32_t)F + (uint32_t)c, drop.seed_lo, drop.seed_hi);
+                ks = drop_keep(hh, drop.sel[0], drop.thr, drop.scale);
+                ka = drop_keep(hh, drop.sel[1], drop.thr, drop.scale);
+                kb = drop_keep(hh, drop.sel[2], drop.thr, drop.scale);
+            }
+            float g = dd ? d_t[c] * sg[c] * ks : 0.0f;
+            if (d_pa && t == ia[c]) g = fmaf(dpa[c], ga[c] * ka, g);
+            if (d_pb && t == ib[c]) g = fmaf(dpb[c], gb[c] * kb, g);
+            bsum[c] += g;
+            gw[c] = g * w;
+        }
+#pragma unroll
+        for (int s8 = 0; s8 < 32; s8 += 8) {
+            if ((m >> s8) & 0xFFu) {                                                      // (most bytes of a parse's row mask are empty)
+#pragma unroll
+                for (int s = s8; s < s8 + 8; ++s)
+                    if (m & (1u << s)) {                                                  // scalar test: an edge t -> s
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[s][c] += gw[c];
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 32; ++s)
+        if (s < T) *reinterpret_cast<float4 *>(dH + ((int64_t)b * T + s) * ldh + f) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+    auto st4 = [](float *p, const float (&v)[4]) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); };
+    if (d_bsum) st4(d_bsum + gf, bsum);
+    if (d_sg) st4(d_sg + gf, acc_sg);
+    if (d_ga) { const float v[4] = {dpa[0] * ya[0], dpa[1] * ya[1], dpa[2] * ya[2], dpa[3] * ya[3]}; st4(d_ga + gf, v); }
+    if (d_gb) { const float v[4] = {dpb[0] * yb[0], dpb[1] * yb[1], dpb[2] * yb[2], dpb[3] * yb[3]}; st4(d_gb + gf, v); }
+}
+
 // out[f] = sum_r X[r, f], deterministic: S row slabs each leave a partial row (fixed order inside a slab: the 4
 // wavefronts take rows r = w, w+4, ... and are added (w0+w1)+(w2+w3)), then the slabs are added in order.
 constexpr int kColsumSlabs = 64;
@@ -252,6 +365,37 @@ int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, c
                            gate_a, gate_b, d_out, ldd, d_pa, d_pb, T, F, n_slabs, dY, ldy, d_sg, d_ga, d_gb, d_bsum, DropSpec{});
     }
     return check_launch("ggcn_gate_pool_backward");
+}
+
+int gate_pool_backward_agg(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
+                           const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
+                           const float *d_pb, const uint32_t *rowmask, int B, int T, int F, float *dH, int64_t ldh,
+                           float *d_sg, float *d_ga, float *d_gb, float *d_bsum, hipStream_t st, const DropSpec *drop)
+{
+    const char *who = "ggcn_gate_pool_backward_agg";
+    if (!out || !dH || !rowmask) return fail(GGCN_EINVAL, "%s: null pointer", who);
+    if (B <= 0 || T <= 0 || F <= 0) return fail(GGCN_EINVAL, "%s: B=%d T=%d F=%d must be positive", who, B, T, F);
+    if (T > 32) return fail(GGCN_EUNSUPPORTED, "%s: T=%d > 32; use ggcn_gate_pool_backward + ggcn_aggregate_t", who, T);
+    if (ldo < F || ldh < F || (d_out && ldd < F)) return fail(GGCN_EINVAL, "%s: leading dimension smaller than F=%d", who, F);
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (F % 4 != 0 || ldo % 4 != 0 || ldh % 4 != 0 || (d_out && ldd % 4 != 0) || !al16(out) || !al16(dH) || !al16(d_out) ||
+        !al16(store_gate) || !al16(gate_a) || !al16(gate_b) || !al16(d_pa) || !al16(d_pb) || !al16(d_sg) || !al16(d_ga) ||
+        !al16(d_gb) || !al16(d_bsum))
+        return fail(GGCN_EUNSUPPORTED, "%s: needs F %% 4 == 0, leading dimensions %% 4 == 0 and 16-byte aligned pointers; use "
+                                       "ggcn_gate_pool_backward + ggcn_aggregate_t", who);
+    const bool dropping = drop && drop->thr != 0;
+    if (dropping && (int64_t)B * T * F >= ((int64_t)1 << 32))
+        return fail(GGCN_EUNSUPPORTED, "%s: gate dropout indexes elements with 32 bits", who);
+    const int n4 = (F + 1023) / 1024;
+    const int64_t blocks = (int64_t)B * n4;
+    if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: grid too large", who);
+    if (dropping)
+        hipLaunchKernelGGL(gate_pool_backward_agg_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, out, ldo, store_gate, gate_a,
+                           gate_b, d_out, ldd, d_pa, d_pb, rowmask, T, F, n4, dH, ldh, d_sg, d_ga, d_gb, d_bsum, *drop);
+    else
+        hipLaunchKernelGGL(gate_pool_backward_agg_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, out, ldo, store_gate, gate_a,
+                           gate_b, d_out, ldd, d_pa, d_pb, rowmask, T, F, n4, dH, ldh, d_sg, d_ga, d_gb, d_bsum, DropSpec{});
+    return check_launch(who);
 }
 
 }  // namespace ggcn

@@ -72,32 +72,45 @@ class _GatedLayerFunction(torch.autograd.Function):
 
         d_out2, d_pa, d_pb = f32c(d_out, (B * T, F)), f32c(d_pa, (B, F)), f32c(d_pb, (B, F))
         out2 = out.reshape(B * T, F)
-        csr_t = csr.transposed()
-        inv = csr.inv_denominators()
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
-            dy = torch.empty(B * T, F, dtype=torch.float32, device=dev)
             need = ctx.needs_input_grad
             d_sg = torch.empty(B, F, dtype=torch.float32, device=dev) if (store_gate is not None and need[3]) else None
             d_ga = torch.empty(B, F, dtype=torch.float32, device=dev) if (gate_a is not None and need[4] and d_pa is not None) else None
             d_gb = torch.empty(B, F, dtype=torch.float32, device=dev) if (gate_b is not None and need[5] and d_pb is not None) else None
             d_bsum = torch.empty(B, F, dtype=torch.float32, device=dev) if (ctx.has_bias and need[2]) else None
-            if ctx.dropout is None:
+            dh = torch.empty(B * T, F, dtype=torch.float32, device=dev)
+            # graphs of up to 32 nodes with a 0/1 adjacency: gate / pool backward AND the transposed aggregation in one launch
+            # (dY is consumed by nothing else: it never reaches memory)
+            one_pass = (T <= 32 and F % 4 == 0 and csr.is_binary and csr.rowmask is not None and csr.rowmask.is_cuda
+                        and os.environ.get("GGCN_BACKWARD_TWO_PASS", "0") != "1")
+            if one_pass:
+                dp, dseed, (ss, sa, sb) = ctx.dropout if ctx.dropout is not None else (0.0, 0, (0, 0, 0))
+                _capi.check(lib.ggcn_gate_pool_backward_agg(
+                    _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),
+                    _capi.ptr(d_out2), F, _capi.ptr(d_pa), _capi.ptr(d_pb), _capi.ptr(csr.rowmask), B, T, F, _capi.ptr(dh), F,
+                    _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), _capi.ptr(d_bsum), float(dp), int(dseed), ss, sa, sb, st),
+                    "ggcn_gate_pool_backward_agg")
+            elif ctx.dropout is None:
+                dy = torch.empty(B * T, F, dtype=torch.float32, device=dev)
                 _capi.check(lib.ggcn_gate_pool_backward(
                     _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),
                     _capi.ptr(d_out2), F, _capi.ptr(d_pa), _capi.ptr(d_pb), B, T, F, _capi.ptr(dy), F,
                     _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), _capi.ptr(d_bsum), st), "ggcn_gate_pool_backward")
             else:   # the keep factors of the forward launch, drawn again from (seed, element)
+                dy = torch.empty(B * T, F, dtype=torch.float32, device=dev)
                 dp, dseed, (ss, sa, sb) = ctx.dropout
                 _capi.check(lib.ggcn_gate_pool_backward_drop(
                     _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),
                     _capi.ptr(d_out2), F, _capi.ptr(d_pa), _capi.ptr(d_pb), B, T, F, _capi.ptr(dy), F,
                     _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), _capi.ptr(d_bsum), float(dp), int(dseed), ss, sa, sb, st),
                     "ggcn_gate_pool_backward_drop")
-            dh = torch.empty(B * T, F, dtype=torch.float32, device=dev)
-            _capi.check(lib.ggcn_aggregate_t(_capi.ptr(dy), F, _capi.ptr(csr_t.rowptr), _capi.ptr(csr_t.colidx),
-                                             _capi.ptr(csr_t.vals), _capi.ptr(inv), B, T, F, _capi.ptr(dh), F, st),
-                        "ggcn_aggregate_t")
+            if not one_pass:
+                csr_t = csr.transposed()
+                inv = csr.inv_denominators()
+                _capi.check(lib.ggcn_aggregate_t(_capi.ptr(dy), F, _capi.ptr(csr_t.rowptr), _capi.ptr(csr_t.colidx),
+                                                 _capi.ptr(csr_t.vals), _capi.ptr(inv), B, T, F, _capi.ptr(dh), F, st),
+                            "ggcn_aggregate_t")
             dx = dw = db = None
             if need[0]:
                 dx = torch.empty(B * T, K, dtype=torch.float32, device=dev)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 10
+#define GGCN_ABI_VERSION 11
 #define GGCN_MASK_MAX_T 256   /* largest graph the row-mask (one-launch) path takes */
 
 typedef void *ggcn_stream_t;
@@ -212,6 +212,16 @@ int ggcn_gate_pool_backward_drop(const float *out, int64_t ldo, const float *sto
                                  const float *d_pb, int B, int T, int F, float *dY, int64_t ldy, float *d_sg,
                                  float *d_ga, float *d_gb, float *d_bsum, float p, uint64_t seed, int stream_store,
                                  int stream_a, int stream_b, ggcn_stream_t stream);
+/* ggcn_gate_pool_backward[_drop] followed by ggcn_aggregate_t in ONE launch, for graphs of T <= 32 nodes with a 0/1 adjacency
+ * given as row masks (ggcn_rowmask_from_dense / _from_csr: one word per node): writes dH = A^T . D . dY (the gradient of
+ * hidden = text . W, models/gcn.py:34,41 under train.py:120) straight away -- dY is consumed by nothing else and never
+ * reaches memory.  p = 0: no gate dropout.  Needs F % 4 == 0, leading dimensions % 4 == 0, 16-byte aligned pointers
+ * (GGCN_EUNSUPPORTED otherwise: take the two calls).  Same sums in the same order as the two calls. */
+int ggcn_gate_pool_backward_agg(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
+                                const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
+                                const float *d_pb, const uint32_t *rowmask, int B, int T, int F, float *dH, int64_t ldh,
+                                float *d_sg, float *d_ga, float *d_gb, float *d_bsum, float p, uint64_t seed,
+                                int stream_store, int stream_a, int stream_b, ggcn_stream_t stream);
 /* d_bsum (NULL or [B,F]) receives sum_t dY per graph; db = sum_rows dY is then ggcn_colsum over its B rows.
  * ggcn_colsum: out[f] = sum_r X[r,f] for X [M, ld], deterministic (fixed-order slab sums);
  * workspace: ggcn_colsum_workspace_bytes(F) bytes. */

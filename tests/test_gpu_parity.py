@@ -468,6 +468,72 @@ def test_layer_backward_vs_oracle_autograd(pkg, dev, precision, fused, B, T, K, 
     _grad_close(m.bias.grad, br.grad, "d bias")
 
 
+@pytest.mark.parametrize("B,T,F,drop", [(7, 32, 256, 0.0), (5, 17, 20, 0.0), (3, 31, 1028, 0.0), (6, 32, 64, 0.3), (1, 1, 8, 0.0)])
+def test_gate_pool_backward_with_the_transposed_aggregation_in_one_launch(pkg, dev, B, T, F, drop):
+    """ggcn_gate_pool_backward_agg (graphs of up to 32 nodes, 0/1 adjacency as row masks): dH = A^T.D.dY straight from the
+    stored layer output, dY never in memory -- against ggcn_gate_pool_backward[_drop] + ggcn_aggregate_t on the same inputs:
+    the gate gradients and the per-graph bias sums bit for bit (the same pass), dH within a few fp32 ulps of its scale (the
+    same sums over t ascending; the two-call path multiplies by 1/(deg+1) inside its own loop), ragged lengths, negative
+    gates, dead columns behind 1024, a one-node graph; and the shapes it must refuse."""
+    from ed_gated_gcn_amd import _capi, synth
+    lib = pkg.load_library()
+    rng = np.random.default_rng(B * 100 + T + F)
+    lens = rng.integers(1, T + 1, size=B)
+    adj = synth.dependency_batch(B, T, min(4.0, T), seed=3, lengths=lens).astype(np.float32)
+    csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj).to(dev))
+    assert csr.is_binary and csr.rowmask is not None
+    out = torch.from_numpy(rng.standard_normal((B * T, F)).astype(np.float32)).to(dev)
+    sg = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32))).to(dev)
+    ga = torch.from_numpy(rng.uniform(-1.0, 1.0, (B, F)).astype(np.float32)).to(dev)
+    gb = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32))).to(dev)
+    d_out = torch.from_numpy(rng.standard_normal((B * T, F)).astype(np.float32)).to(dev)
+    d_pa = torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32)).to(dev)
+    d_pb = torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32)).to(dev)
+    p, st = _capi.ptr, _capi.stream_of(dev)
+    seed = 1234567
+
+    def outs():
+        return [torch.full((B, F), float("nan"), device=dev) for _ in range(4)]
+
+    with torch.cuda.device(dev):
+        dy = torch.empty(B * T, F, device=dev)
+        r_sg, r_ga, r_gb, r_bs = outs()
+        if drop == 0.0:
+            _capi.check(lib.ggcn_gate_pool_backward(p(out), F, p(sg), p(ga), p(gb), p(d_out), F, p(d_pa), p(d_pb), B, T, F, p(dy), F,
+                                                    p(r_sg), p(r_ga), p(r_gb), p(r_bs), st), "ggcn_gate_pool_backward")
+        else:
+            _capi.check(lib.ggcn_gate_pool_backward_drop(p(out), F, p(sg), p(ga), p(gb), p(d_out), F, p(d_pa), p(d_pb), B, T, F, p(dy), F,
+                                                         p(r_sg), p(r_ga), p(r_gb), p(r_bs), drop, seed, 0, 1, 0, st),
+                        "ggcn_gate_pool_backward_drop")
+        csr_t, inv = csr.transposed(), csr.inv_denominators()
+        dh_ref = torch.empty(B * T, F, device=dev)
+        _capi.check(lib.ggcn_aggregate_t(p(dy), F, p(csr_t.rowptr), p(csr_t.colidx), p(csr_t.vals), p(inv), B, T, F, p(dh_ref), F, st),
+                    "ggcn_aggregate_t")
+        dh = torch.full((B * T, F), float("nan"), device=dev)
+        n_sg, n_ga, n_gb, n_bs = outs()
+        rc = lib.ggcn_gate_pool_backward_agg(p(out), F, p(sg), p(ga), p(gb), p(d_out), F, p(d_pa), p(d_pb), p(csr.rowmask), B, T, F,
+                                             p(dh), F, p(n_sg), p(n_ga), p(n_gb), p(n_bs), drop, seed, 0, 1, 0, st)
+        if F % 4 != 0:
+            assert rc == _capi.GGCN_EUNSUPPORTED if hasattr(_capi, "GGCN_EUNSUPPORTED") else rc != 0
+            return
+        _capi.check(rc, "ggcn_gate_pool_backward_agg")
+        for name, u, v in (("d_sg", n_sg, r_sg), ("d_ga", n_ga, r_ga), ("d_gb", n_gb, r_gb), ("d_bsum", n_bs, r_bs)):
+            assert torch.equal(u, v), name
+        scale = float(dh_ref.abs().max()) + 1e-30
+        assert float((dh - dh_ref).abs().max()) <= 4e-7 * scale, float((dh - dh_ref).abs().max()) / scale
+        assert bool(torch.isfinite(dh).all())
+        # float64 statement of the same: dH[s] = sum_t A[t,s] dY[t] / (deg_t + 1)
+        a64 = torch.from_numpy(adj).double()
+        w64 = 1.0 / (a64.sum(2) + 1.0)
+        want = torch.einsum("bts,btf->bsf", a64 * w64[:, :, None], dy.view(B, T, F).double().cpu())
+        assert float((dh.view(B, T, F).double().cpu() - want).abs().max()) <= 2e-6 * scale
+        # refusals: more than 32 nodes, unaligned leading dimension
+        assert lib.ggcn_gate_pool_backward_agg(p(out), F, p(sg), p(ga), p(gb), p(d_out), F, p(d_pa), p(d_pb), p(csr.rowmask), 1, 33, F,
+                                               p(dh), F, None, None, None, None, 0.0, 0, 0, 0, 0, st) != 0
+        assert lib.ggcn_gate_pool_backward_agg(p(out), F + 1, p(sg), p(ga), p(gb), None, F, None, None, p(csr.rowmask), 1, 1, F,
+                                               p(dh), F, None, None, None, None, 0.0, 0, 0, 0, 0, st) != 0
+
+
 @pytest.mark.parametrize("precision,fused", MODES, ids=MODE_IDS)
 def test_gated_block_backward_vs_oracle_autograd(pkg, dev, precision, fused):
     """The whole block of bert_amir5.py:621-640 under autograd: loss touches out, x and xy
