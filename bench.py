@@ -97,6 +97,7 @@ def parse():
                          "the last gathered payload with it bit for bit (tests/test_gpu_parity.py drives this)")
     ap.add_argument("--no-config4", action="store_true",
                     help="N = 1, config 2: skip the compact configs[3] block (a child run of this script with --config 4)")
+    ap.add_argument("--no-box", action="store_true", help="N = 1: skip the `box` block (power / clock under load / MFMA calibration after the timed region)")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch (N > 1 without torch.distributed.run): rendezvous port, 0 = pick a free one")
     a = ap.parse_args()
     d = {2: (4096, 32, 768, 4.0, 4096), 4: (256, 512, 1024, 6.0, 16)}[a.config]
@@ -278,6 +279,171 @@ def ace_block(pkg, synth, torch, dev, precision):
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
+# ---- the state of the box: what makes a figure taken on one MI355X readable on another -------------
+# The block kernel sits at the board's power cap, so its time follows the clock each device holds under an MFMA-dense load.
+# Everything below runs AFTER the timed region; nothing here touches the product kernels or the timed steps.
+MFMA_CALIB_REF_US = 372.0   # ggcn_debug_mfma_calibrate(6144, 24) on the boxes of profiles/r05_box_calibration.json (their median)
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _amd_cards():
+    """sysfs directories of the AMD GPUs with a power sensor: [(card dir, hwmon dir)]."""
+    import glob
+    out = []
+    for hw in sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*")):
+        if _read(os.path.join(hw, "power1_average")) is not None or _read(os.path.join(hw, "power1_input")) is not None:
+            out.append((os.path.dirname(os.path.dirname(hw)), hw))
+    return out
+
+
+class PowerSampler:
+    """Reads board power, power cap and the shader-clock DPM state from sysfs every ~20 ms on a helper thread (plain file
+    reads: no GPU call, no child process) while the caller keeps the GPU busy."""
+
+    def __init__(self):
+        import threading
+        self.cards = _amd_cards()
+        self.samples = {c: [] for c, _ in self.cards}
+        self.sclk = {c: [] for c, _ in self.cards}
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            for card, hw in self.cards:
+                v = _read(os.path.join(hw, "power1_average")) or _read(os.path.join(hw, "power1_input"))
+                if v and v.isdigit():
+                    self.samples[card].append(int(v) / 1e6)
+                cur = [l for l in (_read(os.path.join(card, "pp_dpm_sclk")) or "").splitlines() if l.rstrip().endswith("*")]
+                if cur:
+                    try:
+                        self.sclk[card].append(float(cur[0].split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+                    except (IndexError, ValueError):
+                        pass
+            self._stop.wait(0.02)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=2)
+
+    def summary(self):
+        """The busiest card's figures (on a one-GPU box there is one; on a shared node the loaded card is this process's)."""
+        best = None
+        for card, hw in self.cards:
+            v = self.samples[card]
+            if len(v) >= 3 and (best is None or statistics.mean(v) > statistics.mean(self.samples[best[0]])):
+                best = (card, hw)
+        if best is None:
+            return {"power_w": None, "power_cap_w": None, "sclk_dpm_mhz": None, "note": "no readable power sensor under /sys/class/drm"}
+        card, hw = best
+        v, c = self.samples[card], self.sclk[card]
+        cap = _read(os.path.join(hw, "power1_cap"))
+        return {"power_w": statistics.median(v), "power_w_max": max(v), "power_samples": len(v),
+                "power_cap_w": int(cap) / 1e6 if cap and cap.isdigit() else None,
+                "sclk_dpm_mhz": statistics.median(c) if c else None,
+                "device_unique_id": _read(os.path.join(card, "unique_id")), "card": os.path.basename(os.path.dirname(card))}
+
+
+def clock_from_stamps(stamps):
+    """uint64 [n_wg, 2] = (d s_memtime, d s_memrealtime) per workgroup -> (median clock in MHz, median loop time in us)."""
+    c, w = stamps[:, 0].double(), stamps[:, 1].double()
+    ok = (w > 0) & (c > 0)
+    if int(ok.sum()) == 0:
+        return None, None
+    return float((c[ok] / w[ok]).median()) * 100.0, float(w[ok].median()) * 0.01
+
+
+def box_block(pkg, torch, dev, lib, step, sync_all, ms_per_step, block_args_ok):
+    """`box`: (1) board power / cap / DPM clock sampled from sysfs while the SAME step loop keeps running for ~1 s right after
+    the timed region; (2) the clock the chip holds inside the block kernel's main loop (a diagnostic instantiation that stamps
+    s_memtime / s_memrealtime around it: MI355X_MICROARCH.md 'DVFS give-back' (6)); (3) a fixed MFMA-only calibration launch
+    (csrc/calib.hip: exactly the main-loop matrix-pipe work of the block at config 2, no memory traffic), timed and stamped."""
+    from ed_gated_gcn_amd import _capi
+    box = {}
+    try:
+        with PowerSampler() as ps:
+            t_end = time.perf_counter() + 1.0
+            n_load = 0
+            while time.perf_counter() < t_end:
+                for _ in range(50):
+                    step()
+                n_load += 50
+                sync_all()
+        box.update(ps.summary())
+        box["power_sampled"] = "sysfs, every ~20 ms for ~1 s while %d more untimed steps of the same loop ran, right after the timed region" % n_load
+    except Exception as e:   # noqa: BLE001 -- diagnostics must not cost the headline
+        box["power_error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+    st = _capi.stream_of(dev)
+    # (2) the block kernel's own main loop, stamped
+    if block_args_ok:
+        try:
+            n_wg_max = 1 << 16
+            stamps = torch.zeros(n_wg_max, 2, dtype=torch.int64, device=dev)
+            plain = lib.ggcn_block_fused
+
+            def stamped(*a):
+                return lib.ggcn_debug_block_fused_stamped(*a[:-1], _capi.ptr(stamps), a[-1])
+            lib.ggcn_block_fused = stamped
+            try:
+                ev = []
+                for i in range(60):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); step(); e1.record()
+                    ev.append((e0, e1))
+                torch.cuda.synchronize(dev)
+            finally:
+                lib.ggcn_block_fused = plain
+            live = stamps[stamps[:, 1] > 0]
+            mhz, loop_us = clock_from_stamps(live)
+            box.update({"clock_under_load_mhz": mhz, "block_mainloop_us_per_workgroup": loop_us,
+                        "block_workgroups_stamped": int(live.shape[0]),
+                        "stamped_step_us": statistics.median(a.elapsed_time(b) * 1e3 for a, b in ev[20:]),
+                        "clock_note": "median over the workgroups of the LAST of 60 stamped block launches of d(s_memtime)/d(s_memrealtime) x 100 MHz "
+                                      "around the main loop (diagnostic instantiation; the timed steps execute no stamp)"})
+        except Exception as e:   # noqa: BLE001
+            box["clock_error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+    # (3) MFMA-only calibration: ~0.4 s of back-to-back launches, the last 100 timed by events
+    try:
+        n_wg, stages = 6144, 24
+        cst = torch.zeros(n_wg, 2, dtype=torch.int64, device=dev)
+        sink = torch.zeros(256, device=dev)
+        call = lambda: _capi.check(lib.ggcn_debug_mfma_calibrate(n_wg, stages, _capi.ptr(cst), _capi.ptr(sink), st), "mfma_calibrate")  # noqa: E731
+        for _ in range(1000):
+            call()
+        ev = []
+        for _ in range(100):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); call(); e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize(dev)
+        us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in ev)
+        mhz, loop_us = clock_from_stamps(cst)
+        # 6144 workgroups x 4 wavefronts x 24 stages x (16 fp16 + 8 fp8-MX MFMAs of 32x32) = the block's main-loop MFMAs:
+        # 2 parts x 2*N*K*F algorithmic flops at 128 matrix-pipe cycles per 32^3 block
+        box.update({"mfma_calib_us": us, "mfma_calib_clock_mhz": mhz, "mfma_calib_loop_us_per_workgroup": loop_us,
+                    "mfma_calib_ref_us": MFMA_CALIB_REF_US,
+                    "mfma_calib_note": "ggcn_debug_mfma_calibrate(6144 workgroups, 24 stages): the block kernel's main-loop MFMAs at config 2 on random "
+                                       "register operands, no memory / LDS traffic, two workgroups per CU; median of 100 launches by HIP events behind 1000 "
+                                       "untimed ones; at the nominal 2.4 GHz it would take %.0f us" % (6144 * 4 * 24 * 1024 / 1024 / 2.4e3 / 1.0)})
+        box["headline_at_calib_ms"] = ms_per_step * MFMA_CALIB_REF_US / us
+        box["headline_at_calib_note"] = ("ms_per_step x mfma_calib_ref_us / mfma_calib_us: the raw figure rescaled to a box whose MFMA calibration "
+                                         "equals the reference of profiles/r05_box_calibration.json; a reading aid, never `value`")
+    except Exception as e:   # noqa: BLE001
+        box["calib_error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+    return box
+
+
 def main():
     args = parse()
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
@@ -428,28 +594,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    n_pre = args.precondition
-    if n_pre < 0:   # adaptive: run until the step time has settled (same count on every rank: rank 0 decides)
-        n_pre, last = 0, None
-        while n_pre < 2000:
-            sync_all()
-            t0 = time.perf_counter()
-            for _ in range(50):
-                step()
-            sync_all()
-            dt = time.perf_counter() - t0
-            n_pre += 50
-            settled = last is not None and abs(dt - last) <= 0.01 * dt and n_pre >= 150
-            if dist_on:
-                flag = torch.tensor([1 if settled else 0], device=dev)
-                dist.broadcast(flag, src=0)
-                settled = bool(flag.item())
-            last = dt
-            if settled:
-                break
-    else:
-        for _ in range(n_pre):
-            step()
+    # ---- events and hooks of the timed region, made BEFORE any step runs (round 5): creating and pre-recording them idles the
+    # GPU for milliseconds, and the chip needs tens of steps to ramp back (the driver's `--warmup 5` used to put that ramp inside
+    # the timed region: 950, 839, 792 ... 679 us per step, profiles/r05_driver_cmd_before.txt).  From here on preconditioning,
+    # the W warm-up steps and the K timed steps follow each other with nothing but the contract's barrier + synchronize between.
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides.  HIP events on the launch stream
     # (torch's current stream IS the stream every ggcn_* call is enqueued on) bracket every step and, in eager
     # mode, the launches of the dominant kernel (ggcn_block_fused / ggcn_layer_fused* / ggcn_linear*) on every 4th step.
@@ -463,8 +611,6 @@ def main():
         return evs
     # An event record is a barrier packet on the stream (~2-3 us of GPU time each): with a short step (a small
     # shard) only every 4th step carries the per-launch events and the step events bracket 4 steps at a time.
-    sparse = last is not None and (last / 50) < 300e-6 if args.precondition < 0 else dist_on
-    ev_stride = 4 if sparse else 1
     k_stride = 4          # the per-launch events of the dominant kernel ride on every 4th step (two barrier packets each)
     kernel_events = {}
     kernel_pool = make_events(8 * (args.steps // k_stride + 1)) if graphs is None else []
@@ -491,10 +637,33 @@ def main():
                      "ggcn_aggregate", "ggcn_aggregate_h"):
             hooked[name], w = with_events(name)
             setattr(lib, name, w)
-    # The W warm-up steps of the contract run HERE, after every event and hook of the timed region exists: creating and
-    # pre-recording ~2000 events leaves the GPU idle for ~10 ms, and the ~30 steps after such a gap run up to 40 % slower
-    # while the chip ramps back (GGCN_BENCH_SERIES=1 prints the series) -- the warm-up must end in the state the timed
-    # region starts from.  Between it and t0 there is only the barrier + synchronize the contract asks for.
+    last = None
+    n_pre = args.precondition
+    if n_pre < 0:   # adaptive: run until the step time has settled (same count on every rank: rank 0 decides)
+        n_pre, last = 0, None
+        while n_pre < 2000:
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                step()
+            sync_all()
+            dt = time.perf_counter() - t0
+            n_pre += 50
+            settled = last is not None and abs(dt - last) <= 0.01 * dt and n_pre >= 150
+            if dist_on:
+                flag = torch.tensor([1 if settled else 0], device=dev)
+                dist.broadcast(flag, src=0)
+                settled = bool(flag.item())
+            last = dt
+            if settled:
+                break
+    else:
+        for _ in range(n_pre):
+            step()
+    sparse = last is not None and (last / 50) < 300e-6 if args.precondition < 0 else dist_on
+    ev_stride = 4 if sparse else 1
+    # The W warm-up steps of the contract: they end in the state the timed region starts from.  Between them and t0 there is
+    # only the barrier + synchronize the contract asks for (GGCN_BENCH_SERIES=1 prints the per-step series).
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -629,6 +798,13 @@ def main():
                              n_layers * (lin_flops + agg_flops), fwd_bytes,
                              "per-launch events are not available under graph replay: whole step of this rank's shard")
 
+    # ---- the state of this box, probed right after the timed region (N = 1; diagnostics, see box_block) ----
+    box = None
+    if world == 1 and not dist_on and not args.no_box:
+        box = box_block(pkg, torch, dev, lib, step, sync_all, ms_per_step,
+                        block_args_ok=(args.config == 2 and args.path == "block" and args.precision == "f16mx8" and graphs is None
+                                       and T == 32 and B % 4 == 0 and H % 32 == 0))
+
     # ---- other precisions on the same inputs + accuracy of each against float64 (rank 0's shard) ----
     alt = None
     if not args.no_alt:
@@ -709,6 +885,8 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        if box is not None:
+            result["box"] = box
         if rccl is not None:
             result["rccl"] = rccl
         if gather_check is not None:

@@ -40,6 +40,9 @@ PROTOTYPES = {
     "ggcn_absmax": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "ggcn_range_flag": (c_i32, [c_vp, c_i32, c_vp]),
     "ggcn_debug_poison_lds": (c_i32, [ctypes.c_uint32, c_vp]),
+    "ggcn_debug_mfma_calibrate": (c_i32, [c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "ggcn_debug_block_fused_stamped": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                               c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "ggcn_subword_pool": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                                   c_i32, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_weight_pack_bytes": (c_sz, [c_i32, c_i32, c_i32]),
@@ -71,7 +74,7 @@ PROTOTYPES = {
     "ggcn_gate_overlap": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 PREC = {"bf16x3": 0, "fp32": 1, "f16mx8": 2, "f16": 3, "f16mx6": 4}
 PACKED = ("bf16x3", "f16mx8", "f16", "f16mx6")  # precisions whose linear reads a ggcn_weight_pack image ("f16": half features only)
 FLAG_WEIGHTED = 1

@@ -277,6 +277,23 @@ int ggcn_absmax(const void *X, int is_half, int64_t ld, int64_t M, int K, float 
 
 int ggcn_debug_poison_lds(uint32_t pattern, ggcn_stream_t stream) { return poison_lds(pattern, as_stream(stream)); }
 
+int ggcn_debug_mfma_calibrate(int n_wg, int stages, uint64_t *stamps, float *sink, ggcn_stream_t stream)
+{
+    return mfma_calibrate(n_wg, stages, reinterpret_cast<unsigned long long *>(stamps), sink, as_stream(stream));
+}
+
+int ggcn_debug_block_fused_stamped(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
+                                   const void *graph_ops2, const float *bias1, const float *bias_mid, const float *bias2, int B,
+                                   int T, int K, int F, const float *gate1, const float *gate2, float *gcn1, int64_t ld1,
+                                   float *x_out, int64_t ld2, float *x1, float *y1, float *pool_out, float *overlap_partial,
+                                   int precision, uint64_t *stamps, ggcn_stream_t stream)
+{
+    if (!stamps) return fail(GGCN_EINVAL, "ggcn_debug_block_fused_stamped: null stamp buffer");
+    return block_fused(X, ldx, wpack1, wpack12, graph_ops, graph_ops2, bias1, bias_mid, bias2, B, T, K, F, gate1, gate2, gcn1, ld1,
+                       x_out, ld2, x1, y1, pool_out, overlap_partial, precision, as_stream(stream),
+                       reinterpret_cast<unsigned long long *>(stamps));
+}
+
 int ggcn_range_flag(uint32_t *flag, int clear, ggcn_stream_t stream)
 {
     if (!flag) return fail(GGCN_EINVAL, "ggcn_range_flag: null flag pointer");

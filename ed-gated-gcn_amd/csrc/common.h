@@ -80,7 +80,9 @@ int dropout_mask(int64_t rows, int F, float p, uint64_t seed, int sel, float *ou
 int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops, const void *graph_ops2,
                 const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
                 const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
-                float *x1, float *y1, float *pool_out, float *overlap_partial, int precision, hipStream_t st);
+                float *x1, float *y1, float *pool_out, float *overlap_partial, int precision, hipStream_t st,
+                unsigned long long *stamps = nullptr);
+int mfma_calibrate(int n_wg, int stages, unsigned long long *stamps, float *sink, hipStream_t st);   // calib.hip (diagnostics)
 int overlap_reduce(const float *partials, int B, int F, float *xy, hipStream_t st);
 
 int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,

@@ -35,6 +35,7 @@ struct FusedArgs {
     int g_tiles, n_wg, n_parts, k_steps;
     LayerPart part[2];
     DropSpec drop;              // training-mode keep masks of the gates (thr = 0: none); one part only
+    unsigned long long *stamps; // diagnostics only (ggcn_debug_block_fused_stamped): [workgroup][2] = d(s_memtime), d(s_memrealtime) around the main loop
 };
 
 

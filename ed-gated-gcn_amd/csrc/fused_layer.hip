@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256) void graph_operands2_kernel(const uint32_t *__
 // SCH: 0 = bf16x3 main loop, 1 = f16mx8 (f16mx8_core.h)
 // FULLT: T == 32 and B % 4 == 0 (every row of every tile is a real node): drops every guard.
 // VST: the [N,F] output leaves through LDS as 16-byte row stores (needs F, ldo multiples of 4 and a 16-byte aligned out)
-template <int SCH, bool AVEC, bool KFULL, bool FULLT, bool VST>
+// STAMP (diagnostic instantiation only, ggcn_debug_block_fused_stamped): thread 0 of every workgroup stamps s_memtime (shader
+// cycles) and s_memrealtime (100 MHz) around the main loop into a.stamps, a buffer nothing else reads -- the clock the chip
+// holds under THIS kernel's load (MI355X_MICROARCH.md "DVFS give-back" (6)).  No product launch executes a stamp.
+template <int SCH, bool AVEC, bool KFULL, bool FULLT, bool VST, bool STAMP = false>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(const FusedArgs a)
 {
     __shared__ __attribute__((aligned(16))) char lds[kLdsBytes + kEpiLdsBytes + GGCN_LAB_LDS_PAD];
@@ -183,6 +186,11 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
     stage_epilogue_operands<kLdsBytes>(a, lp, g0, n_wgi, lds, tid);   // g0 = gt0: one wavefront row
     f32x16 acc[4][RN];
     GGCN_TRACE(4);
+    unsigned long long stamp_c = 0, stamp_w = 0;
+    if constexpr (STAMP) {
+        stamp_c = __builtin_readcyclecounter();
+        stamp_w = __builtin_amdgcn_s_memrealtime();
+    }
     if constexpr (SCH == 0)
         bx3::mainloop<float, AVEC, KFULL, !FULLT>(arow, avalid, wpack, K, a.k_steps, wm, nt0, n_tiles_total, lds, acc);
     else {
@@ -205,6 +213,14 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
         fused_range_verdict<kLdsBytes>(amax, wpack, (int64_t)n_tiles_total * (a.k_steps / 2) * mx8::STAGE_PACK_BYTES, lds, true);
     }
     GGCN_TRACE(5);
+    if constexpr (STAMP) {
+        asm volatile("" :: "v"(acc[3][RN - 1][15]));   // the loop's last MFMA has retired
+        const unsigned long long c1 = __builtin_readcyclecounter(), w1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && a.stamps) {
+            a.stamps[2 * (size_t)blockIdx.x] = c1 - stamp_c;
+            a.stamps[2 * (size_t)blockIdx.x + 1] = w1 - stamp_w;
+        }
+    }
     if constexpr (((GGCN_LAB_OFF) & 128) != 0) {   // ladder: no epilogue (the accumulators only have to stay live)
         float s = 0.0f;
 #pragma unroll
@@ -373,7 +389,11 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
         else if (avec) GGCN_LAUNCH(SC, true, false, false, false);                    \
         else GGCN_LAUNCH(SC, false, false, false, false);                             \
     } while (0)
-    if (precision == GGCN_PREC_F16MX8) GGCN_PICK(1);
+    if (a.stamps) {   // the diagnostic instantiation exists for the benchmark's shape class only
+        if (!(precision == GGCN_PREC_F16MX8 && avec && kfull && fullt && vst))
+            return fail(GGCN_EUNSUPPORTED, "%s: the stamped form takes f16mx8, T = 32, B %% 4 == 0, K %% 32 == 0, 16-byte rows", who);
+        hipLaunchKernelGGL((layer_fused_kernel<1, true, true, true, true, true>), dim3((unsigned)grid), dim3(kThreads), 0, st, a);
+    } else if (precision == GGCN_PREC_F16MX8) GGCN_PICK(1);
     else GGCN_PICK(0);
 #undef GGCN_PICK
 #undef GGCN_LAUNCH
@@ -460,7 +480,8 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
 int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
                 const void *graph_ops2, const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
                 const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,
-                float *x1, float *y1, float *pool_out, float *overlap_partial, int precision, hipStream_t st)
+                float *x1, float *y1, float *pool_out, float *overlap_partial, int precision, hipStream_t st,
+                unsigned long long *stamps)
 {
     if (!gate1 || !gate2) return fail(GGCN_EINVAL, "ggcn_block_fused: gate1 and gate2 are required");
     if (!x1 || !y1) return fail(GGCN_EINVAL, "ggcn_block_fused: x1 and y1 are required");
@@ -472,6 +493,7 @@ int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpa
         return fail(GGCN_EINVAL, "ggcn_block_fused: graph_ops2 (ggcn_graph_operands2 blocks, 16-byte aligned) is required");
     a.X = X; a.ldx = ldx; a.graph_ops = static_cast<const char *>(graph_ops); a.graph_ops2 = static_cast<const char *>(graph_ops2);
     a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = 2;
+    a.stamps = stamps;
     // bert_amir5.py:626-636: gcn1 (ungated; optional here), x1 = max_t gcn1*gate1, y1 = max_t gcn1*gate2
     a.part[0] = LayerPart{static_cast<const char *>(wpack1), bias1, nullptr, nullptr, gate1, gate2,
                           gcn1, x1, y1, overlap_partial, (int)ld1};

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 11
+#define GGCN_ABI_VERSION 12
 #define GGCN_MASK_MAX_T 256   /* largest graph the row-mask (one-launch) path takes */
 
 typedef void *ggcn_stream_t;
@@ -403,6 +403,25 @@ int ggcn_range_flag(uint32_t *flag, int clear, ggcn_stream_t stream);
  * process's history (models/gcn.py:41 and bert_amir5.py:635-640 have no such state).  The parity tests run every
  * LDS-resident path behind several patterns (+inf, -inf, NaN / id 0xFFFF) and demand bit-identical outputs. */
 int ggcn_debug_poison_lds(uint32_t pattern, ggcn_stream_t stream);
+
+/* ---- box calibration (diagnostics for bench.py's `box` block; never on the product path) ---------
+ * The block kernel runs at the board's power cap, so its time follows the clock a given device holds under an MFMA-dense
+ * load (devices differ by > 10 %).  Two probes make a figure taken on one box readable on another:
+ * ggcn_debug_mfma_calibrate launches n_wg workgroups (256 threads, two per CU) that issue, per wavefront and stage, the
+ * matrix-pipe work of the f16mx8 main loop -- 16 v_mfma_f32_32x32x16_f16 + 8 v_mfma_scale_f32_32x32x64_f8f6f4 on random
+ * register operands -- and nothing else (no memory or LDS traffic, no barrier).  n_wg = 6144, stages = 24 is exactly the
+ * main-loop MFMA work of ggcn_block_fused at BASELINE config 2.  stamps (NULL or uint64[2 * n_wg]) receives per workgroup
+ * {d(s_memtime) in shader cycles, d(s_memrealtime) in 10 ns ticks} around its loop: clock under load = cycles / ticks x 100 MHz.
+ * ggcn_debug_block_fused_stamped is ggcn_block_fused through a diagnostic instantiation of the same kernel that takes the
+ * same two stamps around ITS main loop (f16mx8, T = 32, B % 4 == 0, K % 32 == 0, 16-byte aligned rows only; stamps
+ * uint64[2 * workgroups], workgroups = ceil(B/16) * ceil(F/256) * 8): same results, a few percent slower; no product launch
+ * executes a stamp. */
+int ggcn_debug_mfma_calibrate(int n_wg, int stages, uint64_t *stamps, float *sink, ggcn_stream_t stream);
+int ggcn_debug_block_fused_stamped(const float *X, int64_t ldx, const void *wpack1, const void *wpack12,
+                                   const void *graph_ops, const void *graph_ops2, const float *bias1, const float *bias_mid,
+                                   const float *bias2, int B, int T, int K, int F, const float *gate1, const float *gate2,
+                                   float *gcn1, int64_t ld1, float *x_out, int64_t ld2, float *x1, float *y1, float *pool_out,
+                                   float *overlap_partial, int precision, uint64_t *stamps, ggcn_stream_t stream);
 
 /* ---- sub-word -> word pooling (the step before the path) ---------------
  * Replaces models/bert_amir5.py:600 `x = torch.bmm(transform, x)`:
