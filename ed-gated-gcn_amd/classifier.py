@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .csr import tensor_version
-from .gated_block import gated_gcn_block
+from .gated_block import gated_gcn_block, takes_block_path
 from .gcn import GraphConvolution
 from .heads import gate_mlps, scores_and_kl
 from .pooling import subword_pool
@@ -72,8 +72,13 @@ class GatedGCNEventDetector(nn.Module):
         self._auto_precision = getattr(opt, "ggcn_precision", None) is None and "GGCN_PRECISION" not in os.environ
         self._assigned = (self.gc1.precision, self.gc2.precision)   # what _assign / the constructor last put there (_auto)
         self._proved = None
+        # train.py:227 keeps the logits of an evaluation batch and nothing else; with opt.ggcn_eval_logits_only = True the
+        # inference forward computes only what they need -- `out` (bert_amir5.py:640,643): the W12 tiles of the block, no
+        # [B,T,H] store of x, no regulariser, no scores / kl head -- and returns (logits, None, None, None)
+        self.eval_logits_only = bool(getattr(opt, "ggcn_eval_logits_only", False))
 
     F16_RANGE_MARGIN = 32752.0   # half of fp16's largest finite value
+    F16MX8_WINDOW = 448.0        # include/ggcn.h GGCN_RANGE_WINDOW: beyond it an activation's fp8 correction saturates
 
     def _auto(self):
         """Still choosing the layers' precision ourselves?  A precision assigned to gc1 / gc2 after construction
@@ -86,9 +91,12 @@ class GatedGCNEventDetector(nn.Module):
         self.gc1.precision = self.gc2.precision = precision
         self._assigned = (precision, precision)
 
-    def _proved_precision(self, csr):
-        """"f16mx8" when every value that kernel rounds to fp16 is bounded below ``F16_RANGE_MARGIN`` by the weights alone,
-        else "bf16x3".  The block's input is the BiLSTM output (``:610``), |x| < 1 (o * tanh(c)); with a 0/1 adjacency a
+    def _proved_precision(self, csr, x=None):
+        """"f16mx8" when every value that kernel rounds to fp16 is bounded below ``F16_RANGE_MARGIN`` by the weights alone
+        AND every activation an f16mx8 main loop splits stays inside its accuracy window (``F16MX8_WINDOW``: the sticky
+        range flag trips beyond it, ``range_guard`` raises) -- else "bf16x3".  The block's input is |x| < 1; where the block
+        does not run as one launch (graphs of more than 32 nodes: LitBank, ACE cased) gc2's main loop splits gcn1, so its
+        bound ``m1`` must stay inside the window too.  The block's input is the BiLSTM output (``:610``), |x| < 1 (o * tanh(c)); with a 0/1 adjacency a
         layer's output is a mean of hidden rows plus the bias (``gcn.py:35,41,43``), so
         ``|x.W1| <= c1 = colsum|W1|``, ``|gcn1| <= m1 = max(c1 + |b1|)``, ``|gcn1.W2| <= m1 * colsum|W2|``, and for the one-launch
         block ``|x.W12| + |mid| <= colsum|W1.W2| + |b1.W2|``.  One host read per weight update (cached on the parameters'
@@ -109,8 +117,17 @@ class GatedGCNEventDetector(nn.Module):
                 bound = torch.stack([m1.new_tensor(1.0), m1, m1 * w2.abs().sum(0).max(),
                                      (w12.abs().sum(0) + (b1 @ w2).abs()).max()]).max()
                 ok = bool(torch.isfinite(bound)) and float(bound) < self.F16_RANGE_MARGIN
-            self._proved = (key, "f16mx8" if ok else "bf16x3")
-        return self._proved[1]
+            self._proved = (key, ok, float(m1))
+        _, ok, m1 = self._proved
+        if ok and not (m1 <= self.F16MX8_WINDOW):
+            # gcn1 may leave the window: fine only where no main loop ever splits it -- the one-launch block
+            before = (self.gc1.precision, self.gc2.precision)
+            self.gc1.precision = self.gc2.precision = "f16mx8"
+            try:
+                ok = x is not None and takes_block_path(x, csr, self.gc1, self.gc2)
+            finally:
+                self.gc1.precision, self.gc2.precision = before
+        return "f16mx8" if ok else "bf16x3"
 
     def forward(self, inputs):
         B = inputs["sentence_length"].shape[0]                              # :579-589
@@ -140,15 +157,19 @@ class GatedGCNEventDetector(nn.Module):
             if self._auto():
                 if isinstance(adj, torch.Tensor):
                     adj = self.gc1._as_csr(adj, x)   # (the block would convert it anyway; identity-cached)
-                self._assign(self._proved_precision(adj))
+                self._assign(self._proved_precision(adj, x))
+            want = ("out",) if self.eval_logits_only else None     # train.py:227: logits only -> only `out` of the block
             if nogate:   # :736-752: gc2(gc1(x)) and its max-pool -- the block with unit gates (one launch for T <= 32)
                 ones = x.new_ones(B, 2 * self.hidden_dim)
-                r = gated_gcn_block(x, adj, ones, ones, self.gc1, self.gc2)
+                r = gated_gcn_block(x, adj, ones, ones, self.gc1, self.gc2, want=want)
                 xy = 0.0
             else:
                 gate1, gate2 = gate_mlps(aspect.contiguous(), self.gate1, self.gate2)     # :562-571,621-622, one launch
-                r = gated_gcn_block(x, adj, gate1, gate2, self.gc1, self.gc2)             # :626-640, one launch (T <= 32)
+                r = gated_gcn_block(x, adj, gate1, gate2, self.gc1, self.gc2, want=want)  # :626-640, one launch (T <= 32)
                 xy = r["xy"]
+            if self.eval_logits_only:
+                cat = [aspect, r["out"], pooled] if v54 else [anchor_rep, aspect, r["out"]]
+                return self.dense(torch.cat(cat, dim=1)), None, None, None               # :533 / :643
             if v54:      # :531-536: dense on [aspect, out, pooled]; fc = Linear o Sigmoid, and sigmoid(cat) = cat(sigmoid)
                 logits = self.dense(torch.cat([aspect, r["out"], pooled], dim=1))
                 scores, kl = scores_and_kl(torch.sigmoid(r["x"]), torch.sigmoid(aspect), logits, self.fc[1], dist)

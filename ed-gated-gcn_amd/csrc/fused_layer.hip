@@ -483,8 +483,12 @@ int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpa
                 float *x1, float *y1, float *pool_out, float *overlap_partial, int precision, hipStream_t st,
                 unsigned long long *stamps)
 {
-    if (!gate1 || !gate2) return fail(GGCN_EINVAL, "ggcn_block_fused: gate1 and gate2 are required");
-    if (!x1 || !y1) return fail(GGCN_EINVAL, "ggcn_block_fused: x1 and y1 are required");
+    if (!gate2) return fail(GGCN_EINVAL, "ggcn_block_fused: gate2 is required");
+    // train.py:227 keeps the logits only, and those need `out` alone (bert_amir5.py:640,643): with x1 = y1 = gcn1 =
+    // overlap_partial = NULL the W1 column tiles are not launched at all (half of the matrix work) -- the EVAL form
+    const bool layer1 = x1 || y1 || gcn1 || overlap_partial;
+    if (layer1 && (!x1 || !y1 || !gate1))
+        return fail(GGCN_EINVAL, "ggcn_block_fused: layer 1's outputs go together (gate1, x1 and y1; all NULL with gcn1 and overlap_partial = the eval form)");
     if (!x_out && !pool_out) return fail(GGCN_EINVAL, "ggcn_block_fused: neither x nor its pool requested");
     if ((gcn1 && ld1 > (int64_t)INT32_MAX) || (x_out && ld2 > (int64_t)INT32_MAX))
         return fail(GGCN_EUNSUPPORTED, "ggcn_block_fused: leading dimension too large");
@@ -492,16 +496,23 @@ int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpa
     if (!graph_ops2 || !aligned16(graph_ops2))
         return fail(GGCN_EINVAL, "ggcn_block_fused: graph_ops2 (ggcn_graph_operands2 blocks, 16-byte aligned) is required");
     a.X = X; a.ldx = ldx; a.graph_ops = static_cast<const char *>(graph_ops); a.graph_ops2 = static_cast<const char *>(graph_ops2);
-    a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = 2;
+    a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = layer1 ? 2 : 1;
     a.stamps = stamps;
-    // bert_amir5.py:626-636: gcn1 (ungated; optional here), x1 = max_t gcn1*gate1, y1 = max_t gcn1*gate2
-    a.part[0] = LayerPart{static_cast<const char *>(wpack1), bias1, nullptr, nullptr, gate1, gate2,
-                          gcn1, x1, y1, overlap_partial, (int)ld1};
     // bert_amir5.py:639-640: x = gate2 * gc2(gcn1), out = max_t x.  A NULL mid bias (gc1 without bias) still
     // needs the second aggregation: a vector of zeros cannot be conjured here, so the caller passes one.
     if (!bias_mid) return fail(GGCN_EINVAL, "ggcn_block_fused: bias_mid (W2^T.b1, zeros when gc1 has no bias) is required");
-    a.part[1] = LayerPart{static_cast<const char *>(wpack12), bias2, bias_mid, gate2, gate2, nullptr,
-                          x_out, pool_out, nullptr, nullptr, (int)ld2};
+    const LayerPart second = LayerPart{static_cast<const char *>(wpack12), bias2, bias_mid, gate2, gate2, nullptr,
+                                       x_out, pool_out, nullptr, nullptr, (int)ld2};
+    if (layer1) {
+        // bert_amir5.py:626-636: gcn1 (ungated; optional here), x1 = max_t gcn1*gate1, y1 = max_t gcn1*gate2
+        a.part[0] = LayerPart{static_cast<const char *>(wpack1), bias1, nullptr, nullptr, gate1, gate2,
+                              gcn1, x1, y1, overlap_partial, (int)ld1};
+        a.part[1] = second;
+    } else {
+        if (stamps) return fail(GGCN_EUNSUPPORTED, "ggcn_debug_block_fused_stamped: the eval form is not stamped");
+        if (!a.graph_ops) a.graph_ops = a.graph_ops2;   // (the W12 tiles read graph_ops2 only; launch_fused insists on a block pointer)
+        a.part[0] = second;   // every XCD runs W12 tiles (tile_of_block: the column tiles of a row block share an XCD)
+    }
     return launch_fused("ggcn_block_fused", a, precision, st);
 }
 

@@ -78,14 +78,29 @@ def takes_block_path(x, csr, gc1, gc2):
             and gc1.out_features == gc2.in_features and gc1.out_features == gc2.out_features)
 
 
-def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=True):
+BLOCK_OUTPUTS = ("x1", "y1", "xy", "x", "out")
+
+
+def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=True, want=None):
     """x [B,T,H] fp32, adj dense [B,T,T] or BatchedCSR, gate1/gate2 [B,H], gc1/gc2 GraphConvolution.
 
     Returns the tensors the reference block produces: ``x1``, ``y1``, ``xy``, ``x`` (gated layer-2 output),
     ``out``, and ``gcn1`` (the ungated layer-1 output).  Nothing downstream of ``bert_amir5.py:640`` reads
     gcn1, so in inference it is only produced on request (``want_gcn1=True``; ``None`` otherwise) -- the
     one-launch block never writes it to HBM unless asked.  Under autograd (training) the two layers run as
-    two launches and gcn1 is always returned."""
+    two launches and gcn1 is always returned.
+
+    ``want`` (inference only; default: all of ``BLOCK_OUTPUTS``) names the outputs the caller will read; the others come back
+    as ``None`` and what only they need is not computed.  The reference's evaluation keeps the logits alone
+    (``train.py:227``) and those need just ``out`` (``bert_amir5.py:640,643``): ``want=("out",)`` launches only the W12 column
+    tiles of the one-launch block -- half of the matrix work, no ``[B,T,H]`` store of ``x``, no regulariser -- and ``out`` is the
+    full block's bit for bit (same tiles, same arithmetic)."""
+    want = BLOCK_OUTPUTS if want is None else tuple(want)
+    bad = [k for k in want if k not in BLOCK_OUTPUTS]
+    if bad:
+        raise ValueError("want: unknown output(s) %s (choose from %s; gcn1 has its own flag want_gcn1)" % (bad, list(BLOCK_OUTPUTS)))
+    w_l1 = any(k in want for k in ("x1", "y1", "xy"))   # anything of bert_amir5.py:627-638
+    w_x = "x" in want
     if x.shape[0] == 0:   # empty batch: what the reference's ops give on empty tensors (the mean of nothing is nan)
         gc1._check(x)
         B, T, F = 0, x.shape[1], gc2.out_features
@@ -95,6 +110,14 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
                 "x": x.new_zeros((0, T, F)), "out": z2}
     csr = adj if isinstance(adj, BatchedCSR) else gc1._as_csr(adj, x)
     training = torch.is_grad_enabled() and (gc1._needs_grad(x, gate1, gate2) or gc2._needs_grad(x, gate2))
+    if training and set(want) != set(BLOCK_OUTPUTS):
+        raise RuntimeError("want= selects outputs of the inference block; under autograd every output is produced")
+
+    def pick(r):   # outputs the caller did not ask for are not handed out (whether or not a path had to compute them)
+        for k in BLOCK_OUTPUTS:
+            if k not in want:
+                r[k] = None
+        return r
     if not training and one_launch and takes_block_path(x, csr, gc1, gc2):
         # ---- ONE launch for :626-640 (+ one 1-block launch that finishes :638) ----
         gc1._check(x)
@@ -107,6 +130,8 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
         if x2d.stride(1) != 1:
             x2d = x2d.contiguous()
         for name, g in (("gate1", gate1), ("gate2", gate2)):
+            if g is None and name == "gate1" and not (w_l1 or want_gcn1):
+                continue   # the eval form never reads gate1
             if not (isinstance(g, torch.Tensor) and g.is_cuda and g.dtype == torch.float32
                     and tuple(g.shape) == (B, F) and g.is_contiguous()):
                 raise RuntimeError("%s must be a contiguous float32 [B,F]=[%d,%d] GPU tensor" % (name, B, F))
@@ -114,44 +139,54 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
             st = _capi.stream_of(dev)
             kprec = gc1.kernel_precision(x2d, csr)   # "f16mx6" where the fp6 kernel takes the shape, else "f16mx8"
             pack1, pack12, mid = _block_operands(gc1, gc2, lib, st, precision=kprec)
+            layer1 = w_l1 or want_gcn1   # False: the eval form -- only the W12 column tiles are launched
             gcn1 = torch.empty(B * T, F, dtype=torch.float32, device=dev) if want_gcn1 else None
-            xo = torch.empty(B * T, F, dtype=torch.float32, device=dev)
-            x1 = torch.empty(B, F, dtype=torch.float32, device=dev)
-            y1 = torch.empty(B, F, dtype=torch.float32, device=dev)
+            xo = torch.empty(B * T, F, dtype=torch.float32, device=dev) if w_x else None
+            x1 = torch.empty(B, F, dtype=torch.float32, device=dev) if layer1 else None
+            y1 = torch.empty(B, F, dtype=torch.float32, device=dev) if layer1 else None
             out = torch.empty(B, F, dtype=torch.float32, device=dev)
-            part = torch.empty(B, (F + 63) // 64, dtype=torch.float32, device=dev)
-            xy = torch.empty((), dtype=torch.float32, device=dev)
+            part = torch.empty(B, (F + 63) // 64, dtype=torch.float32, device=dev) if "xy" in want else None
+            xy = torch.empty((), dtype=torch.float32, device=dev) if "xy" in want else None
             b1 = None if gc1.bias is None else gc1.bias.detach()
             b2 = None if gc2.bias is None else gc2.bias.detach()
             _capi.check(lib.ggcn_block_fused(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack1), _capi.ptr(pack12),
                                              _capi.ptr(csr.graph_ops), _capi.ptr(csr.graph_ops2(0 if kprec == "bf16x3" else 1)),
                                              _capi.ptr(b1), _capi.ptr(mid), _capi.ptr(b2),
-                                             B, T, K, F, _capi.ptr(gate1), _capi.ptr(gate2), _capi.ptr(gcn1), F,
+                                             B, T, K, F, _capi.ptr(gate1 if layer1 else None), _capi.ptr(gate2), _capi.ptr(gcn1), F,
                                              _capi.ptr(xo), F, _capi.ptr(x1), _capi.ptr(y1), _capi.ptr(out),
                                              _capi.ptr(part), _capi.PREC[kprec], st), "ggcn_block_fused")
-            _capi.check(lib.ggcn_overlap_reduce(_capi.ptr(part), B, F, _capi.ptr(xy), st), "ggcn_overlap_reduce")
+            if part is not None:
+                _capi.check(lib.ggcn_overlap_reduce(_capi.ptr(part), B, F, _capi.ptr(xy), st), "ggcn_overlap_reduce")
         if kprec in ("f16mx8", "f16mx6"):
             range_guard.after(x.device)
-        return {"gcn1": None if gcn1 is None else gcn1.view(B, T, F), "x1": x1, "y1": y1, "xy": xy,
-                "x": xo.view(B, T, F), "out": out}
+        return pick({"gcn1": None if gcn1 is None else gcn1.view(B, T, F), "x1": x1, "y1": y1, "xy": xy,
+                     "x": None if xo is None else xo.view(B, T, F), "out": out})
     if (not training and gc1.takes_fused_path(x, csr) and gc2.takes_fused_path(x, csr)
             and gc1.out_features == gc2.out_features):
         # two launches in all: layer 1 leaves its share of sum_f x1*y1 per (graph, 64 columns), layer 2's
         # launch adds them up before it starts on its own tiles (:638 costs no launch of its own)
         B, F = x.shape[0], gc1.out_features
+        if not w_l1:   # gc2 needs gcn1 itself, nothing else of layer 1: no pools, no regulariser
+            gcn1, _, _ = gc1.forward_gated(x, csr)
+            x2, out, _ = gc2.forward_gated(gcn1, csr, store_gate=gate2, pool_gate_a=gate2, want_out=w_x, want_pool_a=True)
+            return pick({"gcn1": gcn1 if want_gcn1 else None, "x1": None, "y1": None, "xy": None, "x": x2, "out": out})
         part = torch.empty(B, (F + 63) // 64, dtype=torch.float32, device=x.device)
         xy = torch.empty((), dtype=torch.float32, device=x.device)
         gcn1, x1, y1 = gc1.forward_gated(x, csr, store_gate=None, pool_gate_a=gate1, pool_gate_b=gate2,
                                          want_pool_a=True, want_pool_b=True, overlap_partial=part)   # :626-636
         x2, out, _ = gc2.forward_gated(gcn1, csr, store_gate=gate2, pool_gate_a=gate2, want_pool_a=True,
-                                       overlap_reduce=(part, xy))                                    # :638-640
-        return {"gcn1": gcn1, "x1": x1, "y1": y1, "xy": xy, "x": x2, "out": out}
+                                       want_out=w_x, overlap_reduce=(part, xy))        # :638-640
+        return pick({"gcn1": gcn1, "x1": x1, "y1": y1, "xy": xy, "x": x2, "out": out})
+    if not training and not w_l1:
+        gcn1, _, _ = gc1.forward_gated(x, csr)
+        x2, out, _ = gc2.forward_gated(gcn1, csr, store_gate=gate2, pool_gate_a=gate2, want_out=w_x, want_pool_a=True)
+        return pick({"gcn1": gcn1 if want_gcn1 else None, "x1": None, "y1": None, "xy": None, "x": x2, "out": out})
     gcn1, x1, y1 = gc1.forward_gated(x, csr, store_gate=None, pool_gate_a=gate1, pool_gate_b=gate2,
                                      want_pool_a=True, want_pool_b=True)           # :626-636
     if torch.is_grad_enabled() and (x1.requires_grad or y1.requires_grad):
         xy = (x1 * y1).sum(1).mean()   # differentiable form of :638 (the regulariser is trained on)
     else:
-        xy = gate_overlap(x1, y1)                                                  # :638
+        xy = gate_overlap(x1, y1) if "xy" in want else None                        # :638
     x2, out, _ = gc2.forward_gated(gcn1, csr, store_gate=gate2, pool_gate_a=gate2,
-                                   want_pool_a=True)                               # :639-640
-    return {"gcn1": gcn1, "x1": x1, "y1": y1, "xy": xy, "x": x2, "out": out}
+                                   want_out=training or w_x, want_pool_a=True)   # :639-640
+    return pick({"gcn1": gcn1, "x1": x1, "y1": y1, "xy": xy, "x": x2, "out": out})

@@ -1381,6 +1381,133 @@ def test_one_launch_block_equals_two_launches(pkg, dev, B, T, H, bias, precision
     assert float((upd["x"] - one["x"]).abs().max()) > 10 * tol
 
 
+# ---------------------------------------------------------------- the eval form: only what train.py:227 keeps
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16mx8", "bf16x3"])
+@pytest.mark.parametrize("B,T,H", [(16, 32, 256), (5, 31, 200), (9, 17, 96), (6, 60, 128), (3, 100, 256), (2, 231, 256)])
+def test_eval_form_out_is_the_full_blocks_bit_for_bit(pkg, dev, B, T, H, precision):
+    """train.py:227 keeps the logits of an evaluation batch, and those need `out` alone (bert_amir5.py:640,643):
+    want=("out",) launches only the W12 column tiles of the one-launch block (graphs of <= 32 nodes; longer graphs: the two
+    layers without layer 1's pools, the regulariser and the [B,T,H] store of x) -- `out` is the full block's bit for bit and
+    equals the oracle; what was not asked for is not handed out."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(B * H + T)
+    adj = torch.from_numpy(synth.dependency_batch(B, T, min(4.0, T), seed=5, lengths=rng.integers(2, T + 1, size=B))).to(dev)
+    x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32)).to(dev)
+    g1 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32))).to(dev)
+    g2 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32))).to(dev)
+    (w1, b1), (w2, b2) = synth.layer_params(H, H, seed=1), synth.layer_params(H, H, seed=2)
+    l1, l2 = _layer(pkg, dev, w1, b1, precision), _layer(pkg, dev, w2, b2, precision)
+    with torch.no_grad():
+        full = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2)
+        ev = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, want=("out",))
+        ev_nog1 = pkg.gated_gcn_block(x, adj, None, g2, l1, l2, want=("out",)) if T <= 32 else ev   # the eval form never reads gate1
+        xo = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, want=("x", "out"))
+        l1only = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, want=("x1", "y1", "xy"))
+    assert torch.equal(ev["out"], full["out"]) and torch.equal(ev_nog1["out"], full["out"])
+    assert all(ev[k] is None for k in ("x1", "y1", "xy", "x", "gcn1"))
+    assert torch.equal(xo["out"], full["out"]) and torch.equal(xo["x"], full["x"]) and xo["x1"] is None and xo["xy"] is None
+    assert torch.equal(l1only["x1"], full["x1"]) and torch.equal(l1only["y1"], full["y1"]) and l1only["x"] is None and l1only["out"] is None
+    assert float(l1only["xy"]) == float(full["xy"])
+    t = torch.from_numpy
+    ref = ref_dense.gated_block(x.cpu(), adj.cpu().float(), g1.cpu(), g2.cpu(), t(w1), t(b1), t(w2), t(b2))
+    np.testing.assert_allclose(ev["out"].cpu().numpy(), ref["out"].numpy(), rtol=0, atol=TOL[precision])
+    with pytest.raises(ValueError):
+        pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, want=("logits",))
+    xg = x.clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="autograd"):
+        pkg.gated_gcn_block(xg, adj, g1, g2, l1, l2, want=("out",))
+
+
+@pytest.mark.gpu
+def test_eval_form_through_the_c_abi(pkg, dev):
+    """ggcn_block_fused with x1 = y1 = gcn1 = overlap_partial = NULL (include/ggcn.h: the eval form): pool_out alone, or with
+    x; half-given layer-1 outputs are refused."""
+    from ed_gated_gcn_amd import _capi, synth
+    from ed_gated_gcn_amd.gated_block import _block_operands
+    lib = pkg.load_library()
+    B, T, H = 12, 32, 128
+    rng = np.random.default_rng(3)
+    adj = synth.dependency_batch(B, T, 4.0, seed=2)
+    rp, ci, _ = synth.csr_from_dense_host(adj)
+    csr = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
+    x = torch.from_numpy(rng.standard_normal((B * T, H)).astype(np.float32)).to(dev)
+    g1, g2 = torch.rand(B, H, device=dev), torch.rand(B, H, device=dev)
+    (w1, b1), (w2, b2) = synth.layer_params(H, H, seed=1), synth.layer_params(H, H, seed=2)
+    l1, l2 = _layer(pkg, dev, w1, b1, "f16mx8"), _layer(pkg, dev, w2, b2, "f16mx8")
+    st = _capi.stream_of(dev)
+    pack1, pack12, mid = _block_operands(l1, l2, lib, st, precision="f16mx8")
+    P = _capi.ptr
+
+    def call(gate1, gcn1, xo, x1, y1, out, part):
+        return lib.ggcn_block_fused(P(x), H, P(pack1), P(pack12), P(csr.graph_ops), P(csr.graph_ops2(1)), P(l1.bias.detach()), P(mid),
+                                    P(l2.bias.detach()), B, T, H, H, P(gate1), P(g2), P(gcn1), H, P(xo), H, P(x1), P(y1), P(out), P(part),
+                                    _capi.PREC["f16mx8"], st)
+    e = lambda *s: torch.full(s, float("nan"), device=dev)   # noqa: E731
+    full = dict(xo=e(B * T, H), x1=e(B, H), y1=e(B, H), out=e(B, H), part=e(B, 2))
+    assert call(g1, None, full["xo"], full["x1"], full["y1"], full["out"], full["part"]) == 0
+    out_only, out_x, xo2 = e(B, H), e(B, H), e(B * T, H)
+    assert call(None, None, None, None, None, out_only, None) == 0
+    assert call(None, None, xo2, None, None, out_x, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out_only, full["out"]) and torch.equal(out_x, full["out"]) and torch.equal(xo2, full["xo"])
+    assert call(g1, None, None, full["x1"], None, out_only, None) != 0        # x1 without y1
+    assert b"go together" in lib.ggcn_last_error()
+    assert call(None, None, None, None, None, None, None) != 0               # nothing requested
+
+
+@pytest.mark.gpu
+def test_classifier_eval_logits_only_and_the_window_of_the_automatic_precision(pkg, dev, golden_dir):
+    """opt.ggcn_eval_logits_only: the inference forward returns the same logits bit for bit (and None for what train.py:227
+    drops).  ADVICE r4: the automatic precision must not pick f16mx8 where gc2's main loop splits a gcn1 the weights only
+    bound beyond the accuracy window |x| <= 448 -- graphs of more than 32 nodes run two launches; the one-launch block
+    never splits gcn1 and keeps f16mx8."""
+    import types
+    from oracle.ref_amir55 import BertAmir55Oracle, EncoderStandIn
+    g = np.load(os.path.join(golden_dir, "amir55_full.npz"))
+    oracle = BertAmir55Oracle(EncoderStandIn(int(g["seed_encoder"])), int(g["n_class"]))
+    oracle.seeded_init(torch.Generator().manual_seed(int(g["seed_params"])))
+    inputs = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    models = []
+    for flag in (False, True):
+        opt = types.SimpleNamespace(device=dev, dropout=0.25, polarities_dim=int(g["n_class"]), ggcn_eval_logits_only=flag)
+        m = pkg.GatedGCNEventDetector(EncoderStandIn(int(g["seed_encoder"])), opt)
+        m.load_state_dict(oracle.state_dict())
+        models.append(m.to(dev).eval())
+    with torch.no_grad():
+        logits, xy, kl, scores = models[0](inputs)
+        logits_e, xy_e, kl_e, scores_e = models[1](inputs)
+    assert torch.equal(logits, logits_e) and xy_e is None and kl_e is None and scores_e is None
+    np.testing.assert_allclose(logits_e.cpu().numpy(), g["logits"], rtol=0, atol=1e-3)
+    # training is unaffected by the flag
+    models[1].train(); models[1].dropout.p = 0.0
+    lt, xyt, klt, sct = models[1](inputs)
+    assert sct is not None and torch.is_tensor(xyt)
+    models[1].eval()
+    # ---- the window: scale gc1 so that 448 < m1 = max(colsum|W1| + |b1|) < 32752
+    m = models[0]
+    with torch.no_grad():
+        c1 = float((m.gc1.weight.abs().sum(0) + m.gc1.bias.abs()).max())
+        s = 2000.0 / c1
+        m.gc1.weight.mul_(s); m.gc1.bias.mul_(s)
+        m.gc2.weight.mul_(1.0 / s)       # keeps |gcn1.W2| and |x.W12| where they were
+        oracle.gc1.weight.mul_(s); oracle.gc1.bias.mul_(s); oracle.gc2.weight.mul_(1.0 / s)
+        logits_s, _, _, _ = m(inputs)                    # 31-node graphs: the one-launch block never splits gcn1
+        assert m._auto_precision and m.gc1.precision == "f16mx8"
+        ref_s = oracle.eval()({k: v.cpu() for k, v in inputs.items()})[0]
+        assert float((logits_s.cpu() - ref_s).abs().max()) <= 1e-3 * max(1.0, float(ref_s.abs().max()))
+        m.gc1.check_range()                              # nothing tripped
+        # the same weights on 40-node graphs (two launches: gc2 splits gcn1): bf16x3, and no range report later
+        x40 = torch.rand(4, 40, 2 * m.hidden_dim, device=dev) * 2 - 1
+        from ed_gated_gcn_amd import synth
+        adj40 = torch.from_numpy(synth.dependency_batch(4, 40, 4.0, seed=1)).to(dev)
+        csr40 = m.gc1._as_csr(adj40, x40)
+        assert m._proved_precision(csr40, x40) == "bf16x3"
+        csr31 = m.gc1._as_csr(inputs["dependency_graph"][:, :31, :31].contiguous(), torch.zeros(inputs["dependency_graph"].shape[0], 31, 2 * m.hidden_dim, device=dev))
+        assert m._proved_precision(csr31, torch.zeros(inputs["dependency_graph"].shape[0], 31, 2 * m.hidden_dim, device=dev)) == "f16mx8"
+        assert m._proved_precision(csr31) == "bf16x3"    # without the input nothing proves the one-launch path
+
+
 # ---------------------------------------------------------------- N > 1 product path on one device (SURVEY 8e)
 def _shard_worker(rank, world, port, ret):
     import traceback
