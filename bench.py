@@ -234,6 +234,60 @@ def config4_block(timeout_s=600):
             "measured_by": "child process `bench.py --config 4 --steps 60 --warmup 20` after the headline's timed region"}
 
 
+def shard512_block(ms_full, timeout_s=300):
+    """The scaling ceiling one GPU can measure: the step of a 512-graph shard exactly as rank 0 of 8 would
+    run it -- hipGraph replay of the block, the logits head, one asynchronous all-gather per step over RCCL with a process
+    group of one -- by a child run of this script after the headline's timed region.  t4096/t512 is what 8 GPUs could reach
+    if the collective and the ranks' skew cost nothing; NO scaling curve is measured here."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-dist", "--graphs", "512", "--steps", "400",
+           "--warmup", "100", "--no-cpu-baseline", "--no-alt", "--no-config4", "--no-box"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+    except Exception as e:   # noqa: BLE001 -- the headline must not die with its appendix
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    us = r["ms_per_step"] * 1e3
+    return {"shard512_us": us, "step_us_median": r["step_us"]["median"], "t4096_over_t512": ms_full * 1e3 / us,
+            "hipgraph_replay": r["config"]["hipgraph_replay"], "backend": (r.get("rccl") or {}).get("backend"),
+            "measured_by": "child process `bench.py --gpus 1 --force-dist --graphs 512 --steps 400 --warmup 100`: 512 of the 4096 graphs on ONE GPU, "
+                           "hipGraph replay + logits head + all_gather_into_tensor on RCCL at world size 1",
+            "note": "an upper bound of the 1 -> 8 GPU speed-up from one GPU's view (8 ranks of 512 graphs, free collective); no run on more than "
+                    "one MI355X was made by the builder and no scaling curve exists"}
+
+
+def eval_block(pkg, torch, dev, x, csr, g1, g2, gc1, gc2):
+    """The eval form beside the full block (NOT the headline): train.py:227 keeps the logits only and those need `out` alone
+    (bert_amir5.py:640,643) -- gated_gcn_block(..., want=("out",)) launches only the W12 column tiles.  Same inputs, same
+    process, HIP events, after the timed region."""
+    try:
+        res = {}
+        with torch.no_grad():
+            for name, want in (("full_block_us", None), ("eval_logits_only_us", ("out",))):
+                f = lambda: pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2, want=want)   # noqa: E731
+                for _ in range(120):
+                    f()
+                ts = []
+                for _ in range(8):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        f()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) / 10 * 1e3)
+                res[name] = statistics.median(ts)
+            same = torch.equal(pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2, want=("out",))["out"],
+                               pkg.gated_gcn_block(x, csr, g1, g2, gc1, gc2)["out"])
+        res.update({"out_bitwise_equal_to_full_block": bool(same),
+                    "note": "want=(\"out\",): only the W12 tiles of ggcn_block_fused, no x1 / y1 / xy, no [B,T,H] store of x; an appendix -- the "
+                            "headline keeps all five outputs of SURVEY 8(d); median of 8 x 10 forwards behind 120 untimed ones"})
+        return res
+    except Exception as e:   # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def ace_block(pkg, synth, torch, dev, precision):
     """One gated layer on an ACE-cased-shaped batch (512 graphs x 231 tokens -- ORI_ML of constant.py:267 -- degree 4, hidden
     768, fp32): the one-launch layer (eight wavefronts per graph) against linear + aggregate, timed with HIP events in this
@@ -448,6 +502,9 @@ def main():
     args = parse()
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))
+    # dmabuf IPC (RCCL needs it on this driver): read by the HSA runtime when it initialises, so it is set before torch is even
+    # imported -- a rank started by an outer torch.distributed.run inherits the launcher's environment or gets it here
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -474,7 +531,6 @@ def main():
                 port = sk.getsockname()[1]
             os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(args.master_port or port), "RANK": "0",
                                "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -547,10 +603,14 @@ def main():
             _, pa, pb = gc1.forward_gated(xx, cc, pool_gate_a=a1, pool_gate_b=a2, want_out=True,
                                           want_pool_a=True, want_pool_b=True)
             r = {"x1": pa, "y1": pb, "out": pa}
+            if head is not None:
+                r["payload"] = pkg.dense_head(r["out"], head)
         else:
-            r = pkg.gated_gcn_block(xx, cc, a1, a2, gc1, gc2, one_launch=((path or args.path) == "block"))
-        if head is not None:
-            r["payload"] = torch.mm(r["out"], head)
+            # N > 1: the logits head rides in the launch that finishes xy (ggcn_dense_head): block + head = two launches per step
+            r = pkg.gated_gcn_block(xx, cc, a1, a2, gc1, gc2, one_launch=((path or args.path) == "block"),
+                                    dense_head=None if head is None else (head, None))
+            if head is not None:
+                r["payload"] = r["logits"]
         return r
 
     # the path's only collective: all-gather of the per-shard logits [B_r, 34] (or pooled outputs [B_r, H]), launched
@@ -715,7 +775,7 @@ def main():
                 with torch.no_grad():
                     full = pkg.gated_gcn_block(x_all.to(dev), csr_a, g1_all.to(dev), g2_all.to(dev), gc1, gc2,
                                                one_launch=(args.path == "block"))["out"]
-                    want = torch.cat([torch.mm(full[l:h], head) if head is not None else full[l:h] for l, h in parts], 0)
+                    want = torch.cat([pkg.dense_head(full[l:h], head) if head is not None else full[l:h] for l, h in parts], 0)
                 diff = float((got.float() - want).abs().max()) if got is not None else float("nan")
                 gather_check = {"bitwise_equal": bool(got is not None and torch.equal(got, want)), "max_abs_diff": diff,
                                 "rows": int(want.shape[0]),
@@ -915,8 +975,11 @@ def main():
                                                   args.cpu_graphs, one_layer)
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
         if world == 1 and args.config == 2 and not args.no_config4:
+            if args.path == "block" and not one_layer:
+                result["eval_logits_only"] = eval_block(pkg, torch, dev, x, csr, g1, g2, gc1, gc2)
             result["ace_cased"] = ace_block(pkg, synth, torch, dev, args.precision if args.precision in ("bf16x3", "f16mx8") else "f16mx8")
             result["config4"] = config4_block()
+            result["scaling_ceiling"] = shard512_block(ms_per_step)
         print(json.dumps(result), flush=True)
     if dist_on:
         dist.barrier()

@@ -21,7 +21,7 @@ from .csr import BatchedCSR  # noqa: F401
 from .gcn import GraphConvolution  # noqa: F401
 from .gated_block import gated_gcn_block  # noqa: F401
 from .pooling import subword_pool  # noqa: F401
-from .heads import gate_mlps, scores_and_kl  # noqa: F401
+from .heads import dense_head, gate_mlps, scores_and_kl  # noqa: F401
 from .classifier import GatedGCNEventDetector, GatedGCNEventDetector54, GCNEventDetectorNoGate, LegacyBertAdapter  # noqa: F401
 
 __all__ = ["GraphConvolution", "gated_gcn_block", "BatchedCSR", "subword_pool", "gate_mlps", "scores_and_kl", "GatedGCNEventDetector", "GatedGCNEventDetector54", "GCNEventDetectorNoGate", "LegacyBertAdapter",

@@ -328,6 +328,12 @@ int ggcn_scores_head(const float *X, int64_t ldx, const float *aspect, int64_t l
                        kl_part, as_stream(stream));
 }
 
+int ggcn_dense_head(const float *pooled, int64_t ldp, const float *Wt, int64_t ldw, const float *bias, int B, int H, int C,
+                    float *logits, int64_t ldl, const float *overlap_partials, int F_block, float *xy, ggcn_stream_t stream)
+{
+    return dense_head(pooled, ldp, Wt, ldw, bias, B, H, C, logits, ldl, overlap_partials, F_block, xy, as_stream(stream));
+}
+
 size_t ggcn_overlap_workspace_bytes(int B) { return overlap_workspace_bytes(B); }
 
 int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,

@@ -98,7 +98,7 @@ int colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *works
 
 size_t dweight_workspace_bytes(int64_t N, int K, int F);
 size_t dweight_bx3_workspace_bytes(int64_t N, int K, int F);
-bool dweight_tn_takes(const float *X, int64_t ldx, const float *G, int64_t ldg, int K, int F);   // dweight_tn.hip
+bool dweight_tn_takes(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F);   // dweight_tn.hip
 size_t dweight_tn_workspace_bytes(int64_t N, int K, int F);
 int dweight_tn(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F, float *dW, int64_t lddw,
                void *workspace, hipStream_t st);
@@ -123,6 +123,9 @@ int gate_mlp(const float *aspect, int64_t lda, int B, int H, const float *w1t_a,
 int scores_head(const float *X, int64_t ldx, const float *aspect, int64_t lda, const float *logits, int64_t ldl,
                 const float *fcw, int64_t ldw, const float *fcb, const float *dist, int64_t ldd, int B, int T, int H,
                 int C, float *scores, int64_t lds_, float *kl_part, hipStream_t st);
+
+int dense_head(const float *pooled, int64_t ldp, const float *Wt, int64_t ldw, const float *bias, int B, int H, int C,
+               float *logits, int64_t ldl, const float *partials, int F_block, float *xy, hipStream_t st);
 
 size_t overlap_workspace_bytes(int B);
 int gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,

@@ -159,7 +159,7 @@ int dweight_bx3(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_
     if (ldx < K || ldg < F || lddw < F) return fail(GGCN_EINVAL, "ggcn_dweight: leading dimension too small");
     if (!aligned16(workspace)) return fail(GGCN_EINVAL, "ggcn_dweight: workspace must be 16-byte aligned");
     // 16-byte aligned rows: the native TN form (dweight_tn.hip: both operands read as they lie, no transpose / pack pass)
-    if (dweight_tn_takes(X, ldx, G, ldg, K, F) && !getenv("GGCN_DWEIGHT_TRANSPOSE")) return dweight_tn(X, ldx, G, ldg, N, K, F, dW, lddw, workspace, st);
+    if (dweight_tn_takes(X, ldx, G, ldg, N, K, F) && !getenv("GGCN_DWEIGHT_TRANSPOSE")) return dweight_tn(X, ldx, G, ldg, N, K, F, dW, lddw, workspace, st);
     const Plan p = plan_for(N, K, F);
     if (p.ksteps_total > 65535 * 16 || p.n_pad > (int64_t)INT32_MAX)
         return fail(GGCN_EUNSUPPORTED, "ggcn_dweight: too many node rows for the bf16x3 form");

@@ -277,7 +277,10 @@ TnPlan tn_plan(int64_t N, int K, int F)
     int64_t s = 8 * (int64_t)per_xcd;
     const int64_t max_s = (N + 511) / 512;   // at least 512 node rows per chunk
     if (s > max_s) s = max_s;
-    if (const char *e = getenv("GGCN_LAB_DW_SPLITS")) s = atoi(e);   // (development: tools/dw_timing.py)
+#ifdef GGCN_LAB_DW   // lab builds only (tools/dw_timing.py through tools/labbuild.sh "-DGGCN_LAB_DW"): the product plan is a pure
+                     // function of (N, K, F), so ggcn_dweight_workspace_bytes and ggcn_dweight can never disagree about the slabs
+    if (const char *e = getenv("GGCN_LAB_DW_SPLITS")) s = atoi(e);
+#endif
     if (s < 1) s = 1;
     p.n_splits = (int)s;
     const int64_t rows = (N + s - 1) / s;
@@ -288,9 +291,13 @@ TnPlan tn_plan(int64_t N, int K, int F)
 
 }  // namespace
 
-bool dweight_tn_takes(const float *X, int64_t ldx, const float *G, int64_t ldg, int K, int F)
+bool dweight_tn_takes(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t N, int K, int F)
 {
-    return (ldx % 4 == 0) && (ldg % 4 == 0) && (K % 4 == 0) && (F % 4 == 0) && aligned16(X) && aligned16(G);
+    if (!((ldx % 4 == 0) && (ldg % 4 == 0) && (K % 4 == 0) && (F % 4 == 0) && aligned16(X) && aligned16(G))) return false;
+    if (N <= 0 || K <= 0 || F <= 0) return false;
+    // a chunk's rows sit behind one buffer resource (2 GiB): wider rows keep the transpose form (dweight_bx3.hip)
+    const TnPlan p = tn_plan(N, K, F);
+    return (p.chunk_rows + TN_NODES) * (ldx > ldg ? ldx : ldg) * 4 < ((int64_t)1 << 31);
 }
 
 size_t dweight_tn_workspace_bytes(int64_t N, int K, int F)

@@ -143,6 +143,66 @@ __global__ __launch_bounds__(256) void scores_head_kernel(const float *__restric
     (void)red;
 }
 
+
+// ---- dense head on the pooled output (bert_amir5.py:643: the share of `dense` that reads the block's `out`) ------------
+// logits[b,c] = bias[c] + sum_k pooled[b,k] * Wt[k,c], C <= 64.  One workgroup of 16 wavefronts per 8 sentences: their pooled
+// rows go to LDS, lane = class, wavefront w takes k-slice w (Wt rows are read coalesced and all at once), the slices
+// meet in LDS in a fixed order: a row's logits do not depend on which batch (or shard) the row sits in.  The LAST workgroup
+// of the launch, when the caller passes them, adds the regulariser's partials of a ggcn_block_fused launch (bert_amir5.py:638)
+// in reduce_partials' order (fused_common.h) -- the one-workgroup ggcn_overlap_reduce launch rides along: at a 512-graph shard
+// the two tail launches were 13 us of a 95 us step, this one is ~4.
+constexpr int kHeadRows = 8, kHeadThreads = 1024, kHeadWaves = kHeadThreads / 64;
+__global__ __launch_bounds__(kHeadThreads) void dense_head_kernel(const float *__restrict__ pooled, int64_t ldp, const float *__restrict__ Wt,
+                                                                  int64_t ldw, const float *__restrict__ bias, int B, int H, int C,
+                                                                  float *__restrict__ logits, int64_t ldl, const float *__restrict__ part,
+                                                                  int n_part, float *__restrict__ xy, int head_blocks)
+{
+    extern __shared__ float head_lds[];   // [kHeadRows][H] pooled rows, then [kHeadWaves][kHeadRows][64] partial sums
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= head_blocks) {   // the regulariser's final sum (one workgroup; fixed order: deterministic)
+        float sdot = 0.0f;
+        for (int idx = tid; idx < n_part; idx += kHeadThreads) sdot += part[idx];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sdot += __shfl_xor(sdot, d);
+        if (lane == 0) head_lds[wave] = sdot;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kHeadWaves; ++w) t += head_lds[w];
+            *xy = t / (float)B;
+        }
+        return;
+    }
+    const int b0 = blockIdx.x * kHeadRows;
+    float *rows = head_lds, *red = head_lds + kHeadRows * H;
+    for (int i = tid; i < kHeadRows * H; i += kHeadThreads) {   // the workgroup's pooled rows, read once and coalesced
+        const int r = i / H, k = i - r * H;
+        rows[i] = b0 + r < B ? pooled[(int64_t)(b0 + r) * ldp + k] : 0.0f;
+    }
+    __syncthreads();
+    // lane = class, wavefront w = k-slice w of 16: every Wt row of the slice is one coalesced load, all of them independent
+    const int kq = (H + kHeadWaves - 1) / kHeadWaves, k0 = wave * kq, k1 = k0 + kq < H ? k0 + kq : H;
+    const int c = lane < C ? lane : 0;
+    float acc[kHeadRows] = {};
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) {
+        const float w = Wt[(int64_t)k * ldw + c];
+#pragma unroll
+        for (int r = 0; r < kHeadRows; ++r) acc[r] = fmaf(rows[r * H + k], w, acc[r]);   // (an LDS broadcast read)
+    }
+#pragma unroll
+    for (int r = 0; r < kHeadRows; ++r) red[(wave * kHeadRows + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave < kHeadRows && lane < C && b0 + wave < B) {   // wavefront r finishes row r: the 16 slices in ascending order
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kHeadWaves; ++w) t += red[(w * kHeadRows + wave) * 64 + lane];
+        logits[(int64_t)(b0 + wave) * ldl + lane] = t + (bias ? bias[lane] : 0.0f);
+    }
+}
+
 }  // namespace
 
 int transpose_f32(const float *W, int rows, int cols, int64_t ldw, float *Wt, hipStream_t st)
@@ -184,6 +244,22 @@ int scores_head(const float *X, int64_t ldx, const float *aspect, int64_t lda, c
     hipLaunchKernelGGL(scores_head_kernel, dim3((unsigned)B), dim3(256), lds, st, X, ldx, aspect, lda, logits, ldl, fcw, ldw,
                        fcb, dist, ldd, T, H, C, scores, lds_, kl_part);
     return check_launch("ggcn_scores_head");
+}
+
+int dense_head(const float *pooled, int64_t ldp, const float *Wt, int64_t ldw, const float *bias, int B, int H, int C,
+               float *logits, int64_t ldl, const float *partials, int F_block, float *xy, hipStream_t st)
+{
+    if (!pooled || !Wt || !logits) return fail(GGCN_EINVAL, "ggcn_dense_head: null pointer");
+    if ((partials != nullptr) != (xy != nullptr)) return fail(GGCN_EINVAL, "ggcn_dense_head: overlap_partials and xy go together");
+    if (B <= 0 || H <= 0 || C <= 0 || (partials && F_block <= 0)) return fail(GGCN_EINVAL, "ggcn_dense_head: B=%d H=%d C=%d F_block=%d", B, H, C, F_block);
+    if (C > 64) return fail(GGCN_EUNSUPPORTED, "ggcn_dense_head: C=%d classes (one lane per class: at most 64)", C);
+    if (ldp < H || ldw < C || ldl < C) return fail(GGCN_EINVAL, "ggcn_dense_head: leading dimension too small");
+    const int head_blocks = (B + kHeadRows - 1) / kHeadRows;
+    const size_t lds = ((size_t)kHeadRows * H + (size_t)kHeadWaves * kHeadRows * 64) * sizeof(float);
+    if (lds > 64 * 1024) return fail(GGCN_EUNSUPPORTED, "ggcn_dense_head: H=%d needs more than 64 KiB of LDS", H);
+    hipLaunchKernelGGL(dense_head_kernel, dim3((unsigned)(head_blocks + (partials ? 1 : 0))), dim3(kHeadThreads), lds, st, pooled, ldp, Wt, ldw, bias,
+                       B, H, C, logits, ldl, partials, partials ? B * ((F_block + 63) / 64) : 0, xy, head_blocks);
+    return check_launch("ggcn_dense_head");
 }
 
 }  // namespace ggcn

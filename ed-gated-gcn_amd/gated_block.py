@@ -81,7 +81,7 @@ def takes_block_path(x, csr, gc1, gc2):
 BLOCK_OUTPUTS = ("x1", "y1", "xy", "x", "out")
 
 
-def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=True, want=None):
+def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=True, want=None, dense_head=None):
     """x [B,T,H] fp32, adj dense [B,T,T] or BatchedCSR, gate1/gate2 [B,H], gc1/gc2 GraphConvolution.
 
     Returns the tensors the reference block produces: ``x1``, ``y1``, ``xy``, ``x`` (gated layer-2 output),
@@ -94,7 +94,33 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
     as ``None`` and what only they need is not computed.  The reference's evaluation keeps the logits alone
     (``train.py:227``) and those need just ``out`` (``bert_amir5.py:640,643``): ``want=("out",)`` launches only the W12 column
     tiles of the one-launch block -- half of the matrix work, no ``[B,T,H]`` store of ``x``, no regulariser -- and ``out`` is the
-    full block's bit for bit (same tiles, same arithmetic)."""
+    full block's bit for bit (same tiles, same arithmetic).
+
+    ``dense_head=(wt [H,C], bias or None)`` (inference): also returns ``logits = out @ wt (+ bias)``, the share of the
+    classifier's ``dense`` that reads the block's output (``bert_amir5.py:643``) -- on the one-launch path in the SAME small
+    launch that finishes ``xy`` (``ggcn_dense_head``), so the block + head are two launches in all."""
+    if dense_head is not None:
+        from .heads import dense_head as _dense_head
+        if torch.is_grad_enabled() and (gc1._needs_grad(x, gate1, gate2) or gc2._needs_grad(x, gate2)):
+            raise RuntimeError("dense_head= is an inference feature; under autograd apply the classifier's own dense layer")
+        r = _gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1, one_launch, want, _defer_xy=True)
+        part = r.pop("_xy_partials", None)
+        if r["out"] is None:
+            raise RuntimeError("dense_head= needs `out` among want=")
+        if r["out"].shape[0] == 0:
+            r["logits"] = r["out"].new_zeros((0, dense_head[0].shape[1]))
+            return r
+        if part is not None:
+            r["logits"], r["xy"] = _dense_head(r["out"], dense_head[0], dense_head[1], partials=part, f_block=gc2.out_features)
+        else:
+            r["logits"] = _dense_head(r["out"], dense_head[0], dense_head[1])
+        return r
+    return _gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1, one_launch, want)
+
+
+def _gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=True, want=None, _defer_xy=False):
+    """gated_gcn_block proper.  _defer_xy: on the one-launch path leave the regulariser's partial sums under "_xy_partials"
+    instead of launching ggcn_overlap_reduce (the caller's dense head finishes them)."""
     want = BLOCK_OUTPUTS if want is None else tuple(want)
     bad = [k for k in want if k not in BLOCK_OUTPUTS]
     if bad:
@@ -155,12 +181,15 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
                                              B, T, K, F, _capi.ptr(gate1 if layer1 else None), _capi.ptr(gate2), _capi.ptr(gcn1), F,
                                              _capi.ptr(xo), F, _capi.ptr(x1), _capi.ptr(y1), _capi.ptr(out),
                                              _capi.ptr(part), _capi.PREC[kprec], st), "ggcn_block_fused")
-            if part is not None:
+            if part is not None and not _defer_xy:
                 _capi.check(lib.ggcn_overlap_reduce(_capi.ptr(part), B, F, _capi.ptr(xy), st), "ggcn_overlap_reduce")
         if kprec in ("f16mx8", "f16mx6"):
             range_guard.after(x.device)
-        return pick({"gcn1": None if gcn1 is None else gcn1.view(B, T, F), "x1": x1, "y1": y1, "xy": xy,
-                     "x": None if xo is None else xo.view(B, T, F), "out": out})
+        r = pick({"gcn1": None if gcn1 is None else gcn1.view(B, T, F), "x1": x1, "y1": y1, "xy": xy,
+                  "x": None if xo is None else xo.view(B, T, F), "out": out})
+        if _defer_xy and part is not None:
+            r["_xy_partials"] = part
+        return r
     if (not training and gc1.takes_fused_path(x, csr) and gc2.takes_fused_path(x, csr)
             and gc1.out_features == gc2.out_features):
         # two launches in all: layer 1 leaves its share of sum_f x1*y1 per (graph, 64 columns), layer 2's

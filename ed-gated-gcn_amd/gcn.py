@@ -82,8 +82,11 @@ class _GatedLayerFunction(torch.autograd.Function):
             dh = torch.empty(B * T, F, dtype=torch.float32, device=dev)
             # graphs of up to 32 nodes with a 0/1 adjacency: gate / pool backward AND the transposed aggregation in one launch
             # (dY is consumed by nothing else: it never reaches memory)
+            # (its 16-byte accesses need every operand 16-byte aligned: a contiguous view at an odd storage offset takes the two calls)
             one_pass = (T <= 32 and F % 4 == 0 and csr.is_binary and csr.rowmask is not None and csr.rowmask.is_cuda
-                        and os.environ.get("GGCN_BACKWARD_TWO_PASS", "0") != "1")
+                        and os.environ.get("GGCN_BACKWARD_TWO_PASS", "0") != "1"
+                        and all(t is None or t.data_ptr() % 16 == 0
+                                for t in (out2, store_gate, gate_a, gate_b, d_out2, d_pa, d_pb, dh, d_sg, d_ga, d_gb, d_bsum)))
             if one_pass:
                 dp, dseed, (ss, sa, sb) = ctx.dropout if ctx.dropout is not None else (0.0, 0, (0, 0, 0))
                 _capi.check(lib.ggcn_gate_pool_backward_agg(

@@ -102,3 +102,29 @@ def scores_and_kl(x, aspect, logits, fc_linear, dist):
                     "ggcn_scores_head")
         _capi.check(lib.ggcn_overlap_reduce(_capi.ptr(part), B, 1, _capi.ptr(kl), st), "ggcn_overlap_reduce")
     return scores, kl
+
+
+def dense_head(pooled, wt, bias=None, partials=None, f_block=None):
+    """``logits = pooled @ wt (+ bias)`` -- the share of ``bert_amir5.py:643``'s ``dense`` that reads the block's pooled
+    output -- as ONE launch; with ``partials`` (the regulariser's per-graph partial sums of the one-launch block,
+    ``bert_amir5.py:638``) the same launch also finishes ``xy``.  ``wt`` is ``[H, C]`` (the ``nn.Linear`` weight slice
+    transposed), ``C <= 64``.  Returns ``logits`` or ``(logits, xy)``.  A row's logits are the same bits whatever batch or
+    shard the row sits in."""
+    for name, t in (("pooled", pooled), ("wt", wt)):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise RuntimeError("%s must be a float32 2-D GPU tensor with unit column stride (no CPU path exists)" % name)
+    B, H = pooled.shape
+    if wt.shape[0] != H:
+        raise RuntimeError("wt must be [%d, C], got %s" % (H, tuple(wt.shape)))
+    C = wt.shape[1]
+    if bias is not None and not (bias.is_cuda and bias.dtype == torch.float32 and tuple(bias.shape) == (C,) and bias.is_contiguous()):
+        raise RuntimeError("bias must be a contiguous float32 [%d] GPU tensor" % C)
+    lib = _capi.load_library()
+    dev = pooled.device
+    with torch.cuda.device(dev):
+        logits = torch.empty(B, C, dtype=torch.float32, device=dev)
+        xy = torch.empty((), dtype=torch.float32, device=dev) if partials is not None else None
+        _capi.check(lib.ggcn_dense_head(_capi.ptr(pooled), pooled.stride(0), _capi.ptr(wt), wt.stride(0), _capi.ptr(bias), B, H, C,
+                                        _capi.ptr(logits), C, _capi.ptr(partials), int(f_block or 0), _capi.ptr(xy),
+                                        _capi.stream_of(dev)), "ggcn_dense_head")
+    return logits if partials is None else (logits, xy)

@@ -338,6 +338,18 @@ int ggcn_dropout_mask(int64_t rows, int F, float p, uint64_t seed, int stream_id
  * *xy = mean_b sum_f x1*y1, fixed summation order (deterministic), one small launch. */
 int ggcn_overlap_reduce(const float *partials, int B, int F, float *xy, ggcn_stream_t stream);
 
+/* ---- dense head on the block's pooled output (+ the regulariser's final sum) in one launch -----------
+ * Replaces the share of models/bert_amir5.py:643 `logits = self.dense(cat[.., out])` that reads the block's output -- and,
+ * when asked, models/bert_amir5.py:638's final sum, which otherwise is ggcn_overlap_reduce's own launch:
+ *   logits[b,c] = (bias ? bias[c] : 0) + sum_k pooled[b,k] * Wt[k,c]      pooled [B, ldp], Wt [H, ldw] (nn.Linear's weight
+ *   slice, transposed: ggcn_transpose), C <= 64, logits [B, ldl]; plain fp32 FMA chains in a fixed order per row, so a row's
+ *   logits do not depend on the batch (or shard) it sits in -- what every rank all-gathers per step when the batch is sharded;
+ *   overlap_partials / xy (both or neither): the float[B * ceil(F_block/64)] partials of a ggcn_block_fused /
+ *   ggcn_layer_fused launch with B graphs and F_block columns -> *xy = mean_b sum (fixed order; equal to
+ *   ggcn_overlap_reduce's result up to the order of additions). */
+int ggcn_dense_head(const float *pooled, int64_t ldp, const float *Wt, int64_t ldw, const float *bias, int B, int H, int C,
+                    float *logits, int64_t ldl, const float *overlap_partials, int F_block, float *xy, ggcn_stream_t stream);
+
 /* ---- gate-diversity regulariser --------------------------------------------
  * Replaces models/bert_amir5.py:638: *xy = mean_b sum_f x1[b,f]*y1[b,f].
  * x1,y1 [B,F] contiguous, xy one device float.  Deterministic (fixed-order

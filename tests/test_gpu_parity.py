@@ -1508,6 +1508,48 @@ def test_classifier_eval_logits_only_and_the_window_of_the_automatic_precision(p
         assert m._proved_precision(csr31) == "bf16x3"    # without the input nothing proves the one-launch path
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,H,C", [(512, 32, 768, 34), (7, 20, 96, 5), (3, 100, 128, 64)])
+def test_dense_head_rides_with_the_regularisers_final_sum(pkg, dev, B, T, H, C):
+    """ggcn_dense_head: logits = out @ Wt (+ bias) -- the share of bert_amir5.py:643's dense that reads the block's output -- in
+    the launch that finishes xy (bert_amir5.py:638): against float64 / torch, row by row independent of the batch (what the
+    sharded run all-gathers), xy equal to ggcn_overlap_reduce's within the order of additions."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(B + C)
+    adj = torch.from_numpy(synth.dependency_batch(B, T, min(4.0, T), seed=5)).to(dev)
+    x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32)).to(dev)
+    g1, g2 = torch.rand(B, H, device=dev), torch.rand(B, H, device=dev)
+    (w1, b1), (w2, b2) = synth.layer_params(H, H, seed=1), synth.layer_params(H, H, seed=2)
+    l1, l2 = _layer(pkg, dev, w1, b1, "f16mx8"), _layer(pkg, dev, w2, b2, "f16mx8")
+    wt = (torch.randn(H, C, generator=torch.Generator().manual_seed(7)) / H ** 0.5).to(dev)
+    bias = torch.randn(C, generator=torch.Generator().manual_seed(8)).to(dev)
+    with torch.no_grad():
+        plain = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2)
+        r = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, dense_head=(wt, bias))
+        r_nb = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, dense_head=(wt, None), want=("out",))
+    for k in ("x1", "y1", "x", "out"):
+        assert torch.equal(r[k], plain[k]), k
+    assert abs(float(r["xy"]) - float(plain["xy"])) <= 2e-6 * max(1.0, abs(float(plain["xy"])))
+    want = plain["out"].double().cpu() @ wt.double().cpu() + bias.double().cpu()
+    assert float((r["logits"].double().cpu() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert float((r_nb["logits"].double().cpu() - (want - bias.double().cpu())).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert r_nb["xy"] is None
+    # a row's logits are the same bits in any sub-batch (the sharded run compares gathered logits bitwise with the unsharded ones)
+    lo, hi = B // 3, max(B // 3 + 1, 2 * B // 3)
+    sub = pkg.dense_head(plain["out"][lo:hi], wt, bias)
+    assert torch.equal(sub, r["logits"][lo:hi])
+    lib = pkg.load_library()
+    from ed_gated_gcn_amd import _capi
+    P = _capi.ptr
+    assert lib.ggcn_dense_head(P(plain["out"]), H, P(wt), C, None, B, H, C, P(r["logits"]), C, P(plain["out"]), H, None, _capi.stream_of(dev)) != 0   # partials without xy
+    big = torch.zeros(H, 65, device=dev)
+    with pytest.raises(RuntimeError, match="at most 64"):
+        pkg.dense_head(plain["out"], big)
+    xg = x.clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="inference"):
+        pkg.gated_gcn_block(xg, adj, g1, g2, l1, l2, dense_head=(wt, bias))
+
+
 # ---------------------------------------------------------------- N > 1 product path on one device (SURVEY 8e)
 def _shard_worker(rank, world, port, ret):
     import traceback
