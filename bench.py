@@ -322,10 +322,38 @@ def ace_block(pkg, synth, torch, dev, precision):
                     torch.cuda.synchronize()
                     ts.append(e0.elapsed_time(e1) / 10 * 1e3)
             res[name] = statistics.median(ts)
+        # the two-layer block at this length (bert_amir5.py:626-640): all five outputs (two one-launch layers), and the eval form
+        # (train.py:227 keeps the logits: only `out`; Z = D.A.X + one layer launch through W12, no product with W1)
+        ls = []
+        for seed in (1, 2):
+            ww, bb = synth.layer_params(H, H, seed=seed)
+            m = pkg.GraphConvolution(H, H, None).to(dev)
+            m.precision = precision
+            with torch.no_grad():
+                m.weight.copy_(torch.from_numpy(ww)); m.bias.copy_(torch.from_numpy(bb))
+            ls.append(m.eval())
+        with torch.no_grad():
+            for name, want in (("block_all_outputs_us", None), ("block_eval_out_only_us", ("out",))):
+                f = lambda: pkg.gated_gcn_block(x, csr, g1, g2, ls[0], ls[1], want=want)   # noqa: E731
+                for _ in range(60):
+                    f()
+                ts = []
+                for _ in range(6):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        f()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) / 10 * 1e3)
+                res[name] = statistics.median(ts)
         t = res["one_launch"]
         layer_bytes = 2 * B * T * H * 4 + H * H * 4 + nnz * 4 + (B * T + 1) * 4 + 5 * B * H * 4
         return {"workload": "512 graphs x 231 tokens (ACE cased, constant.py:267), degree 4, hidden 768, fp32, 1 gated layer with both gates and pools",
                 "precision": precision, "one_launch_us": t, "linear_plus_aggregate_us": res["linear_plus_aggregate"],
+                "block_all_outputs_us": res["block_all_outputs_us"], "block_eval_out_only_us": res["block_eval_out_only_us"],
+                "block_note": "the two-layer block at this length: two one-launch layers (all five outputs) / the eval form (only `out`: ggcn_aggregate on the "
+                              "features + one layer launch through W12 = W1.W2, ggcn_layer_fused_prebias)",
                 "edges_per_sec": nnz / (t * 1e-6), "hbm_frac": layer_bytes / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "kernel": "layer_fused_wide8_kernel (eight wavefronts per graph x 256 columns, edge-list neighbour sums from an fp32 LDS tile)",
                 "timed": "median of 8 x 10 launches behind 120 untimed ones, HIP events, after the headline's timed region"}

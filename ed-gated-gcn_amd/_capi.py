@@ -30,6 +30,8 @@ PROTOTYPES = {
     "ggcn_graph_operands2": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_layer_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                  c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "ggcn_layer_fused_prebias": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                         c_vp, c_i64, c_vp, c_vp, c_i32, c_vp]),
     "ggcn_block_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                  c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "ggcn_overlap_reduce": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),

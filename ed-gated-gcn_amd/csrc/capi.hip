@@ -93,6 +93,16 @@ int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack, const uint3
                        ldo, pool_a, pool_b, overlap_partial, overlap_in, overlap_out, precision, as_stream(stream));
 }
 
+int ggcn_layer_fused_prebias(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const float *bias,
+                             const float *bias_pre, int B, int T, int K, int F, const float *store_gate,
+                             const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo,
+                             float *pool_a, float *pool_b, int precision, ggcn_stream_t stream)
+{
+    if (!bias_pre) return fail(GGCN_EINVAL, "ggcn_layer_fused_prebias: null bias_pre (ggcn_layer_fused is the plain form)");
+    return layer_fused(X, ldx, wpack, rowmask, nullptr, bias, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out,
+                       ldo, pool_a, pool_b, nullptr, nullptr, nullptr, precision, as_stream(stream), nullptr, bias_pre);
+}
+
 int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
                      const void *graph_ops2, const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
                      const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,

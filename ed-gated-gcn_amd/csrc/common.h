@@ -74,7 +74,7 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,
                 float *overlap_partial, const float *overlap_in, float *overlap_out, int precision, hipStream_t st,
-                const struct DropSpec *drop = nullptr);
+                const struct DropSpec *drop = nullptr, const float *bias_pre = nullptr);
 int dropout_mask(int64_t rows, int F, float p, uint64_t seed, int sel, float *out, hipStream_t st);
 
 int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops, const void *graph_ops2,

@@ -14,6 +14,7 @@ struct LayerPart {
     const char *wpack;          // ggcn_weight_pack image of this part's [K, F] matrix
     const float *bias;          // added after the (last) normalised aggregation, or NULL
     const float *mid;           // NULL: one aggregation.  Else: y = D.A.(D.A.h + mid) + bias
+    const float *pre;           // NULL, or [F] added to `hidden` BEFORE the aggregation (graphs of 33..256 nodes): y = D.A.(h + 1.pre^T) + bias
     const float *store_gate;    // [B,F] or NULL (ones)
     const float *pool_gate_a;   // [B,F] or NULL (ones)
     const float *pool_gate_b;

@@ -462,7 +462,7 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
                 const float *bias, int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,
                 float *overlap_partial, const float *overlap_in, float *overlap_out, int precision, hipStream_t st,
-                const DropSpec *drop)
+                const DropSpec *drop, const float *bias_pre)
 {
     if ((overlap_in == nullptr) != (overlap_out == nullptr))
         return fail(GGCN_EINVAL, "ggcn_layer_fused: overlap_in and overlap_out go together");
@@ -472,8 +472,12 @@ int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *
     a.ov_in = overlap_in; a.ov_out = overlap_out;
     a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = 1;
     if (drop) a.drop = *drop;
-    a.part[0] = LayerPart{static_cast<const char *>(wpack), bias, nullptr, store_gate, pool_gate_a, pool_gate_b,
+    a.part[0] = LayerPart{static_cast<const char *>(wpack), bias, nullptr, bias_pre, store_gate, pool_gate_a, pool_gate_b,
                           out, pool_a, pool_b, overlap_partial, (int)ldo};
+    if (bias_pre && T <= 32)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused_prebias: graphs of <= 32 nodes fold both layers in ggcn_block_fused (its eval form); bias_pre is for 33..256 nodes");
+    if (bias_pre && drop)
+        return fail(GGCN_EUNSUPPORTED, "ggcn_layer_fused_prebias: an inference form (no gate dropout)");
     return launch_fused("ggcn_layer_fused", a, precision, st);
 }
 
@@ -501,11 +505,11 @@ int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpa
     // bert_amir5.py:639-640: x = gate2 * gc2(gcn1), out = max_t x.  A NULL mid bias (gc1 without bias) still
     // needs the second aggregation: a vector of zeros cannot be conjured here, so the caller passes one.
     if (!bias_mid) return fail(GGCN_EINVAL, "ggcn_block_fused: bias_mid (W2^T.b1, zeros when gc1 has no bias) is required");
-    const LayerPart second = LayerPart{static_cast<const char *>(wpack12), bias2, bias_mid, gate2, gate2, nullptr,
+    const LayerPart second = LayerPart{static_cast<const char *>(wpack12), bias2, bias_mid, nullptr, gate2, gate2, nullptr,
                                        x_out, pool_out, nullptr, nullptr, (int)ld2};
     if (layer1) {
         // bert_amir5.py:626-636: gcn1 (ungated; optional here), x1 = max_t gcn1*gate1, y1 = max_t gcn1*gate2
-        a.part[0] = LayerPart{static_cast<const char *>(wpack1), bias1, nullptr, nullptr, gate1, gate2,
+        a.part[0] = LayerPart{static_cast<const char *>(wpack1), bias1, nullptr, nullptr, nullptr, gate1, gate2,
                               gcn1, x1, y1, overlap_partial, (int)ld1};
         a.part[1] = second;
     } else {

@@ -83,6 +83,19 @@ __global__ __launch_bounds__(kThreads, SB == 8 ? 1 : kWavesPerSimd) void layer_f
             mx8::mainloop<float, AVEC, KFULL, true, false, BUF>(arow, avalid, lp.wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc, 0, 4,
                                                                  nullptr, &bx);
         }
+        // `pre` (ggcn_layer_fused_prebias): y = D.A.(hidden + 1.pre^T) + bias -- the folded second layer of the eval form, whose
+        // input rows are already aggregated once (gated_block.py).  Workgroup-uniform; padding rows are nobody's neighbours.
+        if (lp.pre) {
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const int gn = (nt0 + j) * NT + (lane & 31);
+                const float pv = lp.pre[gn < F ? gn : 0];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += pv;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -388,6 +388,14 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
                 gb4[j][k] = pool_gate_b ? (pool_gate_b ? pool_gate_b : dummy)[(int64_t)g * F + cc] : 1.0f;
             }
         }
+    // `pre` (ggcn_layer_fused_prebias): hidden + 1.pre^T goes to the tile -- for the graph's real rows only: the padding rows
+    // (row 255 is the edge lists' filler) stay zero
+    float pre_c[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int gn = (nt0 + j) * NT + c;
+        pre_c[j] = lp.pre ? lp.pre[gn < F ? gn : 0] : 0.0f;
+    }
     const int tile_lane = cg * (256 * 128) + 16 * cl, zero_lane = zero_off + 16 * cl;
     const int n_steps = ((GGCN_LAB_OFF) & 16) ? 1 : 16;   // (timing build: one row step only)
     const bool full_slot = T == 256;
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 128 * rg + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                *reinterpret_cast<float *>(tile_cg + tile_off(row, c >> 2) + (c & 3) * 4) = acc[i][j][r];
+                *reinterpret_cast<float *>(tile_cg + tile_off(row, c >> 2) + (c & 3) * 4) = acc[i][j][r] + (row < T ? pre_c[j] : 0.0f);
             }
         __syncthreads();   // (also: the edge lists are complete)
         if (nt0 + j >= n_tiles_total) continue;   // wavefront-uniform: column tile past F (the barriers above are met)

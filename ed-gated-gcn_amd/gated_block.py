@@ -71,6 +71,49 @@ def _block_operands(gc1, gc2, lib, st, precision=None):
     return gc1._packed_weight(lib, st, precision=precision), cached[1], cached[2]
 
 
+def takes_folded_eval_path(x, csr, gc1, gc2):
+    """True when an evaluation that needs only ``out`` / ``x`` of graphs of 33..256 nodes runs WITHOUT the W1 product:
+    ``Z = D.A.X`` (the aggregation kernel on the features), then ONE one-launch layer on Z with the folded weight
+    ``W12 = W1.W2`` and ``mid = W2^T.b1`` added before its aggregation (``ggcn_layer_fused_prebias``):
+    ``gc2(gc1(X)) = D.A.(Z.W12 + 1.mid^T) + b2`` (``bert_amir5.py:626,639``: no non-linearity between the layers)."""
+    return (32 < csr.T <= 256 and gc1.takes_fused_path(x, csr) and gc2.takes_fused_path(x, csr) and gc1.precision == gc2.precision
+            and gc1.precision in ("f16mx8", "bf16x3") and gc1.out_features == gc2.in_features
+            and gc1.in_features == gc1.out_features == gc2.out_features)
+
+
+def _folded_eval(x, csr, gate2, gc1, gc2, want_x):
+    """``(x or None, out)`` of ``bert_amir5.py:639-640`` through the folded weight, two launches, no product with W1."""
+    gc1._check(x)
+    range_guard.before(x.device)
+    lib = _capi.load_library()
+    B, T, K = x.shape
+    F = gc2.out_features
+    dev = x.device
+    x2d = x.reshape(B * T, K)
+    if x2d.stride(1) != 1:
+        x2d = x2d.contiguous()
+    if not (isinstance(gate2, torch.Tensor) and gate2.is_cuda and gate2.dtype == torch.float32 and tuple(gate2.shape) == (B, F)
+            and gate2.is_contiguous()):
+        raise RuntimeError("gate2 must be a contiguous float32 [B,F]=[%d,%d] GPU tensor" % (B, F))
+    with torch.cuda.device(dev):
+        st = _capi.stream_of(dev)
+        prec = gc1.precision
+        _, pack12, mid = _block_operands(gc1, gc2, lib, st, precision=prec)
+        z = torch.empty(B * T, K, dtype=torch.float32, device=dev)
+        # Z = D.A.X: gcn.py:35,41 applied to the features themselves (no bias, no gate, no pool)
+        _capi.check(lib.ggcn_aggregate(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(csr.vals),
+                                       None, B, T, K, None, None, None, _capi.ptr(z), K, None, None, st), "ggcn_aggregate(D.A.X)")
+        xo = torch.empty(B * T, F, dtype=torch.float32, device=dev) if want_x else None
+        out = torch.empty(B, F, dtype=torch.float32, device=dev)
+        b2 = None if gc2.bias is None else gc2.bias.detach()
+        _capi.check(lib.ggcn_layer_fused_prebias(_capi.ptr(z), K, _capi.ptr(pack12), _capi.ptr(csr.rowmask), _capi.ptr(b2), _capi.ptr(mid),
+                                                 B, T, K, F, _capi.ptr(gate2), _capi.ptr(gate2), None, _capi.ptr(xo), F,
+                                                 _capi.ptr(out), None, _capi.PREC[prec], st), "ggcn_layer_fused_prebias")
+    if prec == "f16mx8":
+        range_guard.after(x.device)
+    return (None if xo is None else xo.view(B, T, F)), out
+
+
 def takes_block_path(x, csr, gc1, gc2):
     """True when the inference block runs as ONE launch: both layers on the one-launch layer path with the
     same arithmetic, and gc1's output width = gc2's (the reference's blocks are square, bert_amir5.py:559-560)."""
@@ -195,6 +238,9 @@ def _gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch
         # two launches in all: layer 1 leaves its share of sum_f x1*y1 per (graph, 64 columns), layer 2's
         # launch adds them up before it starts on its own tiles (:638 costs no launch of its own)
         B, F = x.shape[0], gc1.out_features
+        if not w_l1 and not want_gcn1 and one_launch and takes_folded_eval_path(x, csr, gc1, gc2):
+            x2, out = _folded_eval(x, csr, gate2, gc1, gc2, w_x)      # the eval form of 33..256-node graphs: no product with W1
+            return pick({"gcn1": None, "x1": None, "y1": None, "xy": None, "x": x2, "out": out})
         if not w_l1:   # gc2 needs gcn1 itself, nothing else of layer 1: no pools, no regulariser
             gcn1, _, _ = gc1.forward_gated(x, csr)
             x2, out, _ = gc2.forward_gated(gcn1, csr, store_gate=gate2, pool_gate_a=gate2, want_out=w_x, want_pool_a=True)

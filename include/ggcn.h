@@ -293,6 +293,18 @@ int ggcn_layer_fused(const float *X, int64_t ldx, const void *wpack,
                      float *overlap_partial, const float *overlap_in, float *overlap_out,
                      int precision, ggcn_stream_t stream);
 
+/* The one-launch layer for graphs of 33..256 nodes with a bias added BEFORE the aggregation:
+ *   y = D.A.(X.W + 1.bias_pre^T) + bias  =  D.A.X.W + rowsum(D.A).bias_pre + bias
+ * -- the second half of the folded two-layer block when its input rows are already aggregated once: with Z = D.A.X
+ * (ggcn_aggregate on the features), gc2(gc1(X)) = D.A.(Z.W12 + 1.bias_mid^T) + b2 (models/bert_amir5.py:626,639;
+ * W12 = W1.W2, bias_mid = W2^T.b1), so an evaluation that needs only `out` (train.py:227) never multiplies by W1
+ * (gated_block.py: the eval form for LitBank / ACE-cased lengths, constant.py:227,267).  Other arguments as in
+ * ggcn_layer_fused (row masks required: T > 32; no regulariser partials). */
+int ggcn_layer_fused_prebias(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask,
+                             const float *bias, const float *bias_pre, int B, int T, int K, int F,
+                             const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
+                             float *out, int64_t ldo, float *pool_a, float *pool_b, int precision, ggcn_stream_t stream);
+
 /* ---- the whole gated block in one launch (graphs of <= 32 nodes, binary adjacency, inference) ----
  * Replaces models/bert_amir5.py:626-640 -- gc1, both gates, both max-pools, gc2, its gate and pool -- with
  * ONE launch that reads X once and never writes gcn1 unless asked to.  The reference feeds gc2 with the
