@@ -82,6 +82,11 @@ def parse():
                     help="N > 1: what every rank all-gathers per step -- per-shard logits [B_r, 34] = out . Wd (north_star; the "
                          "out-dependent share of bert_amir5.py:643's dense, 70 KB per rank at 8 GPUs) or the pooled out [B_r, H] itself "
                          "(1.5 MB per rank)")
+    ap.add_argument("--gather-mode", default="async", choices=["async", "graph"],
+                    help="N > 1: async (default) = all_gather_into_tensor(async_op=True) on RCCL's own stream behind every replay, so that step "
+                         "i's gather overlaps step i+1's kernels; graph = the all-gather captured INSIDE the step's hipGraph (one graph launch "
+                         "per step and no cross-stream events: 95 vs 109 us per step at a 512-graph shard with a process group of one, "
+                         "DESIGN.md 6; on 8 GPUs the RCCL kernel then runs serially behind the step -- unmeasured, hence opt-in; equal shards only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the alt_precisions / accuracy legs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to "
@@ -168,11 +173,12 @@ def block_float64(x, adj, g1, g2, w1, b1, w2, b2, one_layer):
     return r
 
 
-def capture_steps(torch, dev, forward):
+def capture_steps(torch, dev, forward, gather_in_graph=None):
     """Two hipGraph copies of one step with their own output buffers: step i's all-gather may still be reading
-    copy i % 2 while step i+1 replays the other one."""
+    copy i % 2 while step i+1 replays the other one.  gather_in_graph(r, k) (--gather-mode graph): called inside the capture
+    right after the step's kernels -- the collective becomes a node of the graph."""
     graphs = []
-    for _ in range(2):
+    for k in range(2):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
@@ -182,6 +188,8 @@ def capture_steps(torch, dev, forward):
         g = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(g):
             r = forward()
+            if gather_in_graph is not None:
+                gather_in_graph(r, k)
         graphs.append((g, r))
     return graphs
 
@@ -364,7 +372,7 @@ def ace_block(pkg, synth, torch, dev, precision):
 # ---- the state of the box: what makes a figure taken on one MI355X readable on another -------------
 # The block kernel sits at the board's power cap, so its time follows the clock each device holds under an MFMA-dense load.
 # Everything below runs AFTER the timed region; nothing here touches the product kernels or the timed steps.
-MFMA_CALIB_REF_US = 372.0   # ggcn_debug_mfma_calibrate(6144, 24) on the boxes of profiles/r05_box_calibration.json (their median)
+MFMA_CALIB_REF_US = 341.0   # ggcn_debug_mfma_calibrate(6144, 24) on the boxes of profiles/r05_box_calibration.json (their median)
 
 
 def _read(path):
@@ -644,6 +652,10 @@ def main():
     # the path's only collective: all-gather of the per-shard logits [B_r, 34] (or pooled outputs [B_r, H]), launched
     # asynchronously so step i's gather (RCCL's stream, xGMI) overlaps step i+1's kernels
     gather = shard.PooledGather(counts, N_CLASS if head is not None else H, dev) if dist_on else None
+    in_graph = dist_on and args.gather_mode == "graph"
+    if in_graph and len(set(counts)) != 1:
+        raise SystemExit("--gather-mode graph needs equal shards (%s); use the default async mode" % counts)
+    gbufs = [torch.empty(world * B, N_CLASS if head is not None else H, device=dev) for _ in range(2)] if in_graph else None
     pending = []
     capture = args.capture == "on" or (args.capture == "auto" and dist_on)
     set_mode(args.precision, args.path)
@@ -651,7 +663,13 @@ def main():
     capture_note = None
     if capture:
         try:
-            graphs = capture_steps(torch, dev, forward)
+            if in_graph:   # RCCL's communicator must exist before a capture may contain a collective: one eager all-gather first
+                with torch.no_grad():
+                    r0 = forward()
+                    dist.all_gather_into_tensor(gbufs[0], (r0["payload"] if head is not None else r0["out"]).contiguous())
+                torch.cuda.synchronize(dev)
+            graphs = capture_steps(torch, dev, forward, (lambda r, k: dist.all_gather_into_tensor(
+                gbufs[k], (r["payload"] if head is not None else r["out"]).contiguous())) if in_graph else None)
         except Exception as e:   # noqa: BLE001 -- a refused capture must not cost the run: eager launches instead
             graphs, capture_note = None, "hipGraph capture refused (%s: %s); eager launches" % (type(e).__name__, str(e)[:200])
             torch.cuda.synchronize(dev)
@@ -670,7 +688,9 @@ def main():
                 g, r = graphs[counter[0] & 1]
                 g.replay()
             counter[0] += 1
-            if dist_on:
+            if in_graph and graphs is not None:
+                last_gathered[0] = gbufs[(counter[0] - 1) & 1]   # (filled by the replay; read after a synchronisation only)
+            elif dist_on:
                 pending.append(gather.start(r["payload"] if head is not None else r["out"]))
         return r
 
@@ -794,7 +814,9 @@ def main():
                 "gather_bytes_per_rank": int(max(counts)) * width * 4,
                 "gather_bytes_total_per_step": int(max(counts)) * width * 4 * world,
                 "payload": "logits [B_r,%d]" % N_CLASS if head is not None else "pooled out [B_r,%d]" % H,
-                "collective": "all_gather_into_tensor, async, one per step; shards padded to the largest B_r"}
+                "collective": ("all_gather_into_tensor captured inside the step's hipGraph, one per step" if in_graph and graphs is not None else
+                               "all_gather_into_tensor, async, one per step; shards padded to the largest B_r"),
+                "gather_mode": "graph" if in_graph and graphs is not None else "async"}
         if args.check_gather and args.scaling == "strong":
             got = last_gathered[0]
             if rank == 0:   # the whole batch on rank 0's GPU, one shard-sized GEMM per rank (same kernels as the ranks ran)

@@ -1682,7 +1682,7 @@ def test_bench_distributed_loop_over_rccl_with_a_process_group_of_one(pkg, dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl",
            "--graphs", "512", "--steps", "12", "--warmup", "3", "--precondition", "8", "--no-alt", "--no-cpu-baseline",
-           "--no-config4", "--check-gather"]
+           "--no-config4", "--check-gather", "--gather-mode", gather_mode]   # graph: the collective captured inside the step's hipGraph (opt-in)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -1690,7 +1690,7 @@ def test_bench_distributed_loop_over_rccl_with_a_process_group_of_one(pkg, dev):
     assert len(lines) == 1, out.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["steps"] == 12
-    assert r["rccl"]["backend"] == "nccl" and r["rccl"]["world_size_seen"] == 1
+    assert r["rccl"]["backend"] == "nccl" and r["rccl"]["world_size_seen"] == 1 and r["rccl"]["gather_mode"] == gather_mode
     assert r["rccl"]["gather_bytes_per_rank"] == 512 * 34 * 4
     assert r["config"]["hipgraph_replay"] is True, r["config"]["capture_note"]
     assert r["gather_check"]["bitwise_equal"] is True and r["gather_check"]["rows"] == 512, r["gather_check"]

@@ -136,4 +136,29 @@ try:
     print("gather captured in the graph: %.1f us per step" % ((time.perf_counter() - t0) / 600 * 1e6))
 except Exception as e:
     print("capture of the all-gather refused:", type(e).__name__, str(e)[:300])
+# block-only graph + EAGER dense head + async gather: does the event behind an eager kernel cost less than behind a graph launch?
+try:
+    with torch.no_grad():
+        gb = []
+        for k in range(2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                r = pkg.gated_gcn_block(x, csr, g1, g2, ls[0], ls[1])
+            gb.append((g, r))
+        gather2 = shard.PooledGather([B], 34, dev)
+        for variant in ("graph(block+xy) + eager mm + async gather", "all in graph + async gather"):
+            pending = []
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(600):
+                while len(pending) > 1: gather2.finish(pending.pop(0))
+                if variant.startswith("graph(block"):
+                    g, r = gb[i & 1]; g.replay(); pay = torch.mm(r["out"], head)
+                else:
+                    g, r = gs[i & 1]; g.replay(); pay = r["payload"]
+                pending.append(gather2.start(pay))
+            while pending: gather2.finish(pending.pop(0))
+            torch.cuda.synchronize()
+            print("%-45s %.1f us per step" % (variant, (time.perf_counter() - t0) / 600 * 1e6), flush=True)
+except Exception as e:
+    print("variant failed:", type(e).__name__, str(e)[:200])
 dist.destroy_process_group()
