@@ -86,10 +86,17 @@ __global__ __launch_bounds__(kThreads, 2) void dweight_tn_kernel(const float *__
                                                                  int m_tiles, int n_wg)
 {
     __shared__ __attribute__((aligned(16))) char lds[kTnLds];
+    // Work item w = split * tiles + tile; block ids that share an XCD (id & 7: observed dispatch, speed only) take a CONTIGUOUS
+    // run of ceil(total / 8) items, so that the tiles of one chunk of rows sit on one XCD -- two at most, split between its
+    // X-feature blocks (tile = m_tile * n_wg + n_wgi) -- and share that chunk's rows through its L2.  Round 4 gave every XCD
+    // whole chunks only: 3 x 18 = 54 of its 64 resident slots at config 2's shape (432 workgroups on 512 slots); now 28 chunks
+    // x 18 tiles = 504.
     const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
     const int tiles = m_tiles * n_wg;
-    const int split = xcd + 8 * (qb / tiles), tile = qb % tiles;
-    if (split >= n_splits) return;  // whole workgroup, before any barrier
+    const int total = n_splits * tiles, per_xcd = (total + 7) >> 3;
+    const int w = xcd * per_xcd + qb;
+    if (qb >= per_xcd || w >= total) return;  // whole workgroup, before any barrier
+    const int split = w / tiles, tile = w - split * tiles;
     const int m_tile = tile / n_wg, n_wgi = tile % n_wg;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -272,9 +279,8 @@ TnPlan tn_plan(int64_t N, int K, int F)
     p.m_tiles = (K + TN_BM - 1) / TN_BM;
     p.n_wg = (F + TN_BN - 1) / TN_BN;
     const int tiles = p.m_tiles * p.n_wg;
-    int per_xcd = 64 / tiles;          // chunks whose workgroups fit an XCD's 64 resident slots at once
-    if (per_xcd < 1) per_xcd = 1;
-    int64_t s = 8 * (int64_t)per_xcd;
+    int64_t s = 512 / tiles;           // as many chunks as fill the chip's 512 resident slots (two workgroups per CU) in ONE round
+    if (s < 8) s = 8;                  // (more tiles than slots: eight chunks, several rounds)
     const int64_t max_s = (N + 511) / 512;   // at least 512 node rows per chunk
     if (s > max_s) s = max_s;
 #ifdef GGCN_LAB_DW   // lab builds only (tools/dw_timing.py through tools/labbuild.sh "-DGGCN_LAB_DW"): the product plan is a pure
@@ -312,7 +318,7 @@ int dweight_tn(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t
     const TnPlan p = tn_plan(N, K, F);
     float *slabs = static_cast<float *>(workspace);
     const int tiles = p.m_tiles * p.n_wg;
-    const int64_t grid = (int64_t)8 * tiles * ((p.n_splits + 7) / 8);
+    const int64_t grid = (int64_t)8 * (((int64_t)p.n_splits * tiles + 7) / 8);   // 8 XCDs x ceil(total / 8) work items
     if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_dweight: too many tiles");
     if ((p.chunk_rows + TN_NODES) * (ldx > ldg ? ldx : ldg) * 4 >= ((int64_t)1 << 31))
         return fail(GGCN_EUNSUPPORTED, "ggcn_dweight: a chunk of %lld rows of %lld floats exceeds the 2 GiB a buffer resource addresses",
