@@ -224,13 +224,19 @@ int ggcn_gate_pool_backward_agg(const float *out, int64_t ldo, const float *stor
                                 const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                                 const float *d_pb, const uint32_t *rowmask, int B, int T, int F, float *dH, int64_t ldh,
                                 float *d_sg, float *d_ga, float *d_gb, float *d_bsum, float p, uint64_t seed, int sel_store,
-                                int sel_a, int sel_b, ggcn_stream_t stream)
+                                int sel_a, int sel_b, float *dh_amax, ggcn_stream_t stream)
 {
     if (!(p >= 0.0f && p < 1.0f) || sel_store < 0 || sel_store > 2 || sel_a < 0 || sel_a > 2 || sel_b < 0 || sel_b > 2)
         return fail(GGCN_EINVAL, "ggcn_gate_pool_backward_agg: p=%g streams %d %d %d", (double)p, sel_store, sel_a, sel_b);
     const DropSpec d = make_drop_spec(p, seed, sel_store, sel_a, sel_b);
     return gate_pool_backward_agg(out, ldo, store_gate, gate_a, gate_b, d_out, ldd, d_pa, d_pb, rowmask, B, T, F, dH, ldh, d_sg,
-                                  d_ga, d_gb, d_bsum, as_stream(stream), p > 0.0f ? &d : nullptr);
+                                  d_ga, d_gb, d_bsum, as_stream(stream), p > 0.0f ? &d : nullptr, dh_amax);
+}
+
+int ggcn_linear_scaled(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy, int64_t M, int K, int F,
+                       const float *amax, ggcn_stream_t stream)
+{
+    return linear_scaled(X, ldx, wpack, Y, ldy, M, K, F, amax, as_stream(stream));
 }
 
 int ggcn_layer_fused_drop(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops,

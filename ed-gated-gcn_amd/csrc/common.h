@@ -45,6 +45,9 @@ int weight_pack(const float *W, int64_t ldw, int K, int F, int precision, bool t
 int linear_packed(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy,
                   int64_t M, int K, int F, int precision, hipStream_t st);
 
+bool linear_scaled_takes(const float *X, int64_t ldx, const float *Y, int64_t ldy, int K, int F);
+int linear_scaled(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy, int64_t M, int K, int F, const float *amax,
+                  hipStream_t st);
 int linear_packed_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M, int K,
                     int F, int precision, hipStream_t st);
 int aggregate_t(const float *G, int64_t ldg, const int32_t *rowptr_t, const int32_t *colidx_t,
@@ -92,7 +95,8 @@ int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, c
 int gate_pool_backward_agg(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                            const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                            const float *d_pb, const uint32_t *rowmask, int B, int T, int F, float *dH, int64_t ldh,
-                           float *d_sg, float *d_ga, float *d_gb, float *d_bsum, hipStream_t st, const struct DropSpec *drop = nullptr);
+                           float *d_sg, float *d_ga, float *d_gb, float *d_bsum, hipStream_t st, const struct DropSpec *drop = nullptr,
+                           float *dh_amax = nullptr);
 size_t colsum_workspace_bytes(int F);
 int colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *workspace, hipStream_t st);
 

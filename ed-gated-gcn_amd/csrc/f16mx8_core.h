@@ -205,11 +205,13 @@ __device__ __forceinline__ BufX<AT> make_bufx(const AT *X, int64_t ldx, int64_t 
 #ifndef GGCN_LAB_W2
 #define GGCN_LAB_W2 0
 #endif
-template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false, bool BUF = false, int NB = 4>
+// XS (ggcn_linear_scaled: the backward's dX): every value is multiplied by the power of two `xscale` before it is split -- rows
+// whose magnitudes lie anywhere in the fp32 range (gradients) are brought to |x| < 256 first; the caller undoes it at the store.
+template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false, bool BUF = false, int NB = 4, bool XS = false>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int stages_packed, int wm,
                                          int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN], int rot = 0, int nblk = 4,
-                                         float *amax_out = nullptr, const BufX<AT> *bufx = nullptr)
+                                         float *amax_out = nullptr, const BufX<AT> *bufx = nullptr, float xscale = 1.0f)
 {
     static_assert(!BUF || (AVEC && KFULL && sizeof(AT) == 4), "buffer loads: whole 16-byte pieces of fp32 rows");
     static_assert(NB >= 1 && NB <= 4 && (NB == 4 || (sizeof(AT) == 4 && !RBLK)), "NB < 4: fp32 rows (pass i = block i), no run-time count");
@@ -264,6 +266,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
                     if constexpr (ZROWS && !BUF) in = in && avalid[i];   // (BUF: padding rows lie outside the descriptor and arrive as zeros)
                     x[c] = in ? x[c] : 0.0f;
                 }
+                if constexpr (XS) x[c] *= xscale;
             }
             sp[q] = split4(x[0], x[1], x[2], x[3], amax);
         }

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void gate_pool_backward_agg_kernel(
     const float *__restrict__ d_out, int64_t ldd, const float *__restrict__ d_pa,
     const float *__restrict__ d_pb, const uint32_t *__restrict__ rowmask, int T, int F, int n_slabs,
     float *__restrict__ dH, int64_t ldh, float *__restrict__ d_sg, float *__restrict__ d_ga, float *__restrict__ d_gb,
-    float *__restrict__ d_bsum, DropSpec drop)
+    float *__restrict__ d_bsum, DropSpec drop, unsigned int *__restrict__ dh_amax)
 {
     const int b = blockIdx.x / n_slabs;
     const int f = (blockIdx.x - b * n_slabs) * 1024 + 4 * threadIdx.x;
@@ -274,6 +274,20 @@ __global__ __launch_bounds__(256) void gate_pool_backward_agg_kernel(
 #pragma unroll
     for (int s = 0; s < 32; ++s)
         if (s < T) *reinterpret_cast<float4 *>(dH + ((int64_t)b * T + s) * ldh + f) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+    if (dh_amax) {   // the largest |dH| of the launch (ggcn_linear_scaled derives its power-of-two scale from it): one atomic per wavefront
+        // (the launcher passes dh_amax only when F % 256 == 0: a wavefront is then wholly inside or wholly past F, and the lane
+        // exchange below reads live lanes only)
+        float m = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {   // v_max3_f32 with |.| modifiers: two values per instruction
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(acc[s][0]), "v"(acc[s][1]));
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(acc[s][2]), "v"(acc[s][3]));
+        }
+        if (!(m <= 3.0e38f)) m = __builtin_inff();      // NaN / inf in the gradients: say so (the scaled linear then leaves the data alone)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if ((threadIdx.x & 63) == 0) atomicMax(dh_amax, __float_as_uint(m));   // non-negative floats order like their bit patterns
+    }
     auto st4 = [](float *p, const float (&v)[4]) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); };
     if (d_bsum) st4(d_bsum + gf, bsum);
     if (d_sg) st4(d_sg + gf, acc_sg);
@@ -370,7 +384,7 @@ int gate_pool_backward(const float *out, int64_t ldo, const float *store_gate, c
 int gate_pool_backward_agg(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
                            const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                            const float *d_pb, const uint32_t *rowmask, int B, int T, int F, float *dH, int64_t ldh,
-                           float *d_sg, float *d_ga, float *d_gb, float *d_bsum, hipStream_t st, const DropSpec *drop)
+                           float *d_sg, float *d_ga, float *d_gb, float *d_bsum, hipStream_t st, const DropSpec *drop, float *dh_amax)
 {
     const char *who = "ggcn_gate_pool_backward_agg";
     if (!out || !dH || !rowmask) return fail(GGCN_EINVAL, "%s: null pointer", who);
@@ -386,15 +400,17 @@ int gate_pool_backward_agg(const float *out, int64_t ldo, const float *store_gat
     const bool dropping = drop && drop->thr != 0;
     if (dropping && (int64_t)B * T * F >= ((int64_t)1 << 32))
         return fail(GGCN_EUNSUPPORTED, "%s: gate dropout indexes elements with 32 bits", who);
+    if (dh_amax && F % 256 != 0)
+        return fail(GGCN_EUNSUPPORTED, "%s: dh_amax needs F %% 256 == 0 (F=%d): whole wavefronts of columns", who, F);
     const int n4 = (F + 1023) / 1024;
     const int64_t blocks = (int64_t)B * n4;
     if (blocks > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: grid too large", who);
     if (dropping)
         hipLaunchKernelGGL(gate_pool_backward_agg_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, out, ldo, store_gate, gate_a,
-                           gate_b, d_out, ldd, d_pa, d_pb, rowmask, T, F, n4, dH, ldh, d_sg, d_ga, d_gb, d_bsum, *drop);
+                           gate_b, d_out, ldd, d_pa, d_pb, rowmask, T, F, n4, dH, ldh, d_sg, d_ga, d_gb, d_bsum, *drop, reinterpret_cast<unsigned int *>(dh_amax));
     else
         hipLaunchKernelGGL(gate_pool_backward_agg_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, out, ldo, store_gate, gate_a,
-                           gate_b, d_out, ldd, d_pa, d_pb, rowmask, T, F, n4, dH, ldh, d_sg, d_ga, d_gb, d_bsum, DropSpec{});
+                           gate_b, d_out, ldd, d_pa, d_pb, rowmask, T, F, n4, dH, ldh, d_sg, d_ga, d_gb, d_bsum, DropSpec{}, reinterpret_cast<unsigned int *>(dh_amax));
     return check_launch(who);
 }
 

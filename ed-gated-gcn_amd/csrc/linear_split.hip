@@ -193,11 +193,26 @@ __device__ __forceinline__ void store_elem(__half *p, float v) { *p = __float2ha
 
 // ET: element type of X and Y (float, or __half with fp32 accumulation); SCH: 0 = bf16x3, 1 = f16mx8
 // VST (fp32 output, F and ldy multiples of 4, Y 16-byte aligned): 16-byte row stores through LDS
-template <int SCH, typename ET, bool AVEC, bool KFULL, bool VST>
+// XS (ggcn_linear_scaled, f16mx8 fast shapes only): *amax (device memory) = the largest |x| of the whole matrix, left there by the
+// kernel that produced X; every workgroup derives the same power of two s from it (|x| * s < 256: inside fp16's range and the fp8
+// correction's window whatever the magnitudes were -- gradients live far below fp16's normal range), multiplies x by s before
+// the split and the accumulators by 1 / s at the store.  Powers of two: both multiplications are exact.
+__device__ __forceinline__ void scale_from_amax(const float *amax, float &s, float &inv_s)
+{
+    const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(*amax));
+    const int e = (int)((bits >> 23) & 0xFFu);          // biased exponent of amax (amax >= 0)
+    int se = 261 - e;                                    // s = 2^(7 - (e - 127)): amax * s in [128, 256)
+    se = se > 230 ? 230 : se;                            // (amax below 2^-96, zero included: a large finite scale)
+    const bool ok = e != 255;                            // inf / NaN: no scaling (the result is inf / NaN either way)
+    s = ok ? __uint_as_float((uint32_t)se << 23) : 1.0f;
+    inv_s = ok ? __uint_as_float((uint32_t)(254 - se) << 23) : 1.0f;
+}
+template <int SCH, typename ET, bool AVEC, bool KFULL, bool VST, bool XS = false>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_split_kernel(
     const ET *__restrict__ X, int64_t ldx, const char *__restrict__ wpack,
-    ET *__restrict__ Y, int64_t ldy, int64_t M, int K, int F, int m_tiles, int n_wg, int k_steps)
+    ET *__restrict__ Y, int64_t ldy, int64_t M, int K, int F, int m_tiles, int n_wg, int k_steps, const float *__restrict__ amax_in = nullptr)
 {
+    static_assert(!XS || (SCH == 1 && AVEC && KFULL && VST && sizeof(ET) == 4), "the scaled form exists for the fast fp32 shapes of f16mx8");
     __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
     int m_tile, n_wgi;
     if (!tile_of_block(blockIdx.x, m_tiles, n_wg, m_tile, n_wgi)) return;  // before any barrier
@@ -236,6 +251,18 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void linear_split_kernel(
             }
             bx = mx8::make_bufx<ET>(X, ldx, m0, M, rel, tid);
         }
+        if constexpr (XS) {
+            float xs, inv_xs;
+            scale_from_amax(amax_in, xs, inv_xs);
+            mx8::mainloop<ET, AVEC, KFULL, false, false, BUF, 4, true>(arow, avalid, wpack, K, k_steps / 2, wm, nt0, n_tiles_total, lds, acc, 0, 4,
+                                                                     nullptr, &bx, xs);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv_xs;
+        } else
         mx8::mainloop<ET, AVEC, KFULL, false, false, BUF>(arow, avalid, wpack, K, k_steps / 2, wm, nt0, n_tiles_total, lds, acc, 0, 4, nullptr, &bx);
     }
 
@@ -498,6 +525,30 @@ int linear_packed(const float *X, int64_t ldx, const void *wpack, float *Y, int6
 {
     if (precision == GGCN_PREC_F16MX8) return launch_linear<1, float>(X, ldx, wpack, Y, ldy, M, K, F, st);
     return launch_linear<0, float>(X, ldx, wpack, Y, ldy, M, K, F, st);
+}
+
+// dX of the backward (train.py:120 through gcn.py:34) on the two-unit f16mx8 product: rows scaled into range by a power of two
+// derived on the device from *amax.  Fast shapes only (K % 32 == 0, F % 4 == 0, 16-byte aligned rows); the caller keeps bf16x3 otherwise.
+bool linear_scaled_takes(const float *X, int64_t ldx, const float *Y, int64_t ldy, int K, int F)
+{
+    return (K % BK == 0) && (ldx % 4 == 0) && aligned16(X) && (int64_t)ldx * 4 * 257 < ((int64_t)1 << 31) && (F % 4 == 0) && (ldy % 4 == 0) && aligned16(Y);
+}
+int linear_scaled(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy, int64_t M, int K, int F, const float *amax,
+                  hipStream_t st)
+{
+    if (!X || !wpack || !Y || !amax) return fail(GGCN_EINVAL, "ggcn_linear_scaled: null pointer");
+    if (M <= 0 || K <= 0 || F <= 0 || ldx < K || ldy < F) return fail(GGCN_EINVAL, "ggcn_linear_scaled: M=%lld K=%d F=%d", (long long)M, K, F);
+    if (!aligned16(wpack)) return fail(GGCN_EINVAL, "ggcn_linear_scaled: wpack must be 16-byte aligned");
+    if (!linear_scaled_takes(X, ldx, Y, ldy, K, F))
+        return fail(GGCN_EUNSUPPORTED, "ggcn_linear_scaled: needs K %% 32 == 0, F %% 4 == 0 and 16-byte aligned rows (use ggcn_linear with GGCN_PREC_BF16X3)");
+    const int k_steps = round_up(K, BK) / KSTEP;
+    const int64_t m_tiles = (M + BM - 1) / BM;
+    const int n_wg = (F + BN - 1) / BN;
+    const int64_t grid = grid_for(m_tiles, n_wg);
+    if (grid > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "ggcn_linear_scaled: M too large");
+    hipLaunchKernelGGL((linear_split_kernel<1, float, true, true, true, true>), dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx,
+                       static_cast<const char *>(wpack), Y, ldy, M, K, F, (int)m_tiles, n_wg, k_steps, amax);
+    return check_launch("ggcn_linear_scaled");
 }
 
 int linear_packed_h(const void *X, int64_t ldx, const void *wpack, void *Y, int64_t ldy, int64_t M,

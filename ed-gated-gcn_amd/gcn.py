@@ -87,13 +87,19 @@ class _GatedLayerFunction(torch.autograd.Function):
                         and os.environ.get("GGCN_BACKWARD_TWO_PASS", "0") != "1"
                         and all(t is None or t.data_ptr() % 16 == 0
                                 for t in (out2, store_gate, gate_a, gate_b, d_out2, d_pa, d_pb, dh, d_sg, d_ga, d_gb, d_bsum)))
+            # dX on the two-unit f16mx8 product (ggcn_linear_scaled): the launch that makes dH also leaves max |dH|, from which the
+            # linear derives a power-of-two scale on the device -- gradients have no range contract of their own
+            dx = None
+            scaled_dx = (one_pass and need[0] and layer.precision == "f16mx8" and K % 4 == 0 and F % 256 == 0
+                         and os.environ.get("GGCN_DX_PRECISION", "f16mx8") == "f16mx8")
+            dh_amax = torch.zeros(1, dtype=torch.float32, device=dev) if scaled_dx else None
             if one_pass:
                 dp, dseed, (ss, sa, sb) = ctx.dropout if ctx.dropout is not None else (0.0, 0, (0, 0, 0))
                 _capi.check(lib.ggcn_gate_pool_backward_agg(
                     _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),
                     _capi.ptr(d_out2), F, _capi.ptr(d_pa), _capi.ptr(d_pb), _capi.ptr(csr.rowmask), B, T, F, _capi.ptr(dh), F,
-                    _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), _capi.ptr(d_bsum), float(dp), int(dseed), ss, sa, sb, st),
-                    "ggcn_gate_pool_backward_agg")
+                    _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), _capi.ptr(d_bsum), float(dp), int(dseed), ss, sa, sb,
+                    _capi.ptr(dh_amax), st), "ggcn_gate_pool_backward_agg")
             elif ctx.dropout is None:
                 dy = torch.empty(B * T, F, dtype=torch.float32, device=dev)
                 _capi.check(lib.ggcn_gate_pool_backward(
@@ -114,10 +120,14 @@ class _GatedLayerFunction(torch.autograd.Function):
                 _capi.check(lib.ggcn_aggregate_t(_capi.ptr(dy), F, _capi.ptr(csr_t.rowptr), _capi.ptr(csr_t.colidx),
                                                  _capi.ptr(csr_t.vals), _capi.ptr(inv), B, T, F, _capi.ptr(dh), F, st),
                             "ggcn_aggregate_t")
-            dx = dw = db = None
+            dw = db = None
             if need[0]:
                 dx = torch.empty(B * T, K, dtype=torch.float32, device=dev)
-                if layer.precision in _capi.PACKED:
+                if scaled_dx:
+                    pack_t = layer._packed_weight(lib, st, transposed=True, precision="f16mx8")
+                    _capi.check(lib.ggcn_linear_scaled(_capi.ptr(dh), F, _capi.ptr(pack_t), _capi.ptr(dx), K, B * T, F, K,
+                                                       _capi.ptr(dh_amax), st), "ggcn_linear_scaled(dX)")
+                elif layer.precision in _capi.PACKED:
                     # gradients can be far below fp16's range (f16mx8 would flush them): dX always takes
                     # the bf16x3 linear, which keeps the fp32 exponent range
                     pack_t = layer._packed_weight(lib, st, transposed=True)
@@ -192,9 +202,9 @@ class GraphConvolution(nn.Module):
         changes; one image per precision is kept ("f16mx6" layers also need the "f16mx8" image for the shapes the
         fp6 kernel does not take)."""
         w = self.weight
-        # the transposed image only serves the backward's dX linear, which is always bf16x3
-        name = precision or self.precision
-        name = name if (name in _capi.PACKED and not transposed) else "bf16x3"
+        # the transposed image serves the backward's dX linear: bf16x3 (full range) unless the caller names f16mx8 (the scaled form)
+        name = precision or (self.precision if not transposed else "bf16x3")
+        name = name if (name in _capi.PACKED and (not transposed or name == "f16mx8")) else "bf16x3"
         prec = _capi.PREC[name]
         key = (w.data_ptr(), tensor_version(w), w.device)
         slot = (name, bool(transposed))

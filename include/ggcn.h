@@ -221,7 +221,18 @@ int ggcn_gate_pool_backward_agg(const float *out, int64_t ldo, const float *stor
                                 const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa,
                                 const float *d_pb, const uint32_t *rowmask, int B, int T, int F, float *dH, int64_t ldh,
                                 float *d_sg, float *d_ga, float *d_gb, float *d_bsum, float p, uint64_t seed,
-                                int stream_store, int stream_a, int stream_b, ggcn_stream_t stream);
+                                int stream_store, int stream_a, int stream_b, float *dh_amax, ggcn_stream_t stream);
+/* dh_amax (NULL, or one device float the caller zeroed): receives max |dH| of the launch (an atomic maximum of bit patterns:
+ * +inf when a gradient is not finite).  ggcn_linear_scaled reads it:
+ *   Y[M,F] = X[M,K] . W   on the two-unit f16mx8 product (GGCN_PREC_F16MX8 image of W) for rows of ANY magnitude: every
+ *   workgroup derives the same power of two s from *amax (|x| * s < 256), multiplies x by s before the split and the result by
+ *   1 / s -- both exact -- so gradients far below fp16's range keep the product's ~2^-16 accuracy relative to the largest
+ *   entry (values below amax * 2^-32 flush: they cannot matter to a sum the largest entries dominate).  This is the backward's
+ *   dX = dH . W^T (train.py:120 through models/gcn.py:34) at 325-335 us instead of the three-product form's 420 at config 2.
+ *   Needs K % 32 == 0, F % 4 == 0 and 16-byte aligned rows (GGCN_EUNSUPPORTED otherwise: ggcn_linear with GGCN_PREC_BF16X3).
+ *   A non-finite amax leaves the data unscaled (the result is non-finite either way). */
+int ggcn_linear_scaled(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy, int64_t M, int K, int F,
+                       const float *amax, ggcn_stream_t stream);
 /* d_bsum (NULL or [B,F]) receives sum_t dY per graph; db = sum_rows dY is then ggcn_colsum over its B rows.
  * ggcn_colsum: out[f] = sum_r X[r,f] for X [M, ld], deterministic (fixed-order slab sums);
  * workspace: ggcn_colsum_workspace_bytes(F) bytes. */

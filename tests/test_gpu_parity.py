@@ -511,8 +511,9 @@ def test_gate_pool_backward_with_the_transposed_aggregation_in_one_launch(pkg, d
                     "ggcn_aggregate_t")
         dh = torch.full((B * T, F), float("nan"), device=dev)
         n_sg, n_ga, n_gb, n_bs = outs()
+        amax = torch.zeros(1, device=dev) if F % 256 == 0 else None      # (the maximum rides along for whole wavefronts of columns)
         rc = lib.ggcn_gate_pool_backward_agg(p(out), F, p(sg), p(ga), p(gb), p(d_out), F, p(d_pa), p(d_pb), p(csr.rowmask), B, T, F,
-                                             p(dh), F, p(n_sg), p(n_ga), p(n_gb), p(n_bs), drop, seed, 0, 1, 0, st)
+                                             p(dh), F, p(n_sg), p(n_ga), p(n_gb), p(n_bs), drop, seed, 0, 1, 0, p(amax), st)
         if F % 4 != 0:
             assert rc == _capi.GGCN_EUNSUPPORTED if hasattr(_capi, "GGCN_EUNSUPPORTED") else rc != 0
             return
@@ -522,6 +523,12 @@ def test_gate_pool_backward_with_the_transposed_aggregation_in_one_launch(pkg, d
         scale = float(dh_ref.abs().max()) + 1e-30
         assert float((dh - dh_ref).abs().max()) <= 4e-7 * scale, float((dh - dh_ref).abs().max()) / scale
         assert bool(torch.isfinite(dh).all())
+        if amax is not None:
+            assert float(amax) == float(dh.abs().max())      # the launch's own max |dH| (what ggcn_linear_scaled scales by)
+        else:
+            one = torch.zeros(1, device=dev)
+            assert lib.ggcn_gate_pool_backward_agg(p(out), F, p(sg), p(ga), p(gb), p(d_out), F, p(d_pa), p(d_pb), p(csr.rowmask), B, T, F,
+                                                   p(dh), F, None, None, None, None, 0.0, 0, 0, 0, 0, p(one), st) != 0
         # float64 statement of the same: dH[s] = sum_t A[t,s] dY[t] / (deg_t + 1)
         a64 = torch.from_numpy(adj).double()
         w64 = 1.0 / (a64.sum(2) + 1.0)
@@ -529,9 +536,50 @@ def test_gate_pool_backward_with_the_transposed_aggregation_in_one_launch(pkg, d
         assert float((dh.view(B, T, F).double().cpu() - want).abs().max()) <= 2e-6 * scale
         # refusals: more than 32 nodes, unaligned leading dimension
         assert lib.ggcn_gate_pool_backward_agg(p(out), F, p(sg), p(ga), p(gb), p(d_out), F, p(d_pa), p(d_pb), p(csr.rowmask), 1, 33, F,
-                                               p(dh), F, None, None, None, None, 0.0, 0, 0, 0, 0, st) != 0
+                                               p(dh), F, None, None, None, None, 0.0, 0, 0, 0, 0, None, st) != 0
         assert lib.ggcn_gate_pool_backward_agg(p(out), F + 1, p(sg), p(ga), p(gb), None, F, None, None, p(csr.rowmask), 1, 1, F,
-                                               p(dh), F, None, None, None, None, 0.0, 0, 0, 0, 0, st) != 0
+                                               p(dh), F, None, None, None, None, 0.0, 0, 0, 0, 0, None, st) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,F,scale", [(4096, 768, 768, 1.0), (300, 96, 64, 3.0e-9), (1000, 256, 128, 2.0e7), (128, 32, 4, 1.0e-30)])
+def test_scaled_f16mx8_linear_for_gradients_of_any_magnitude(pkg, dev, M, K, F, scale):
+    """ggcn_linear_scaled (the backward's dX = dH . W^T, train.py:120): the two-unit f16mx8 product on rows far outside fp16's
+    range -- a power of two derived on the device from max |x| brings them inside first.  Against float64, relative to the
+    result's scale, whatever the magnitude (1e-30 ... 1e7); a column of exact zeros and an outlier row keep their meaning;
+    a non-finite maximum leaves the data alone."""
+    from ed_gated_gcn_amd import _capi
+    lib = pkg.load_library()
+    rng = np.random.default_rng(M + K)
+    x = torch.from_numpy((rng.standard_normal((M, K)) * scale).astype(np.float32)).to(dev)
+    x[:, 3] = 0.0
+    x[M // 2] *= 50.0                                            # an outlier row sets the scale; the others keep ~2^-16 of IT
+    w = torch.from_numpy(rng.uniform(-0.06, 0.06, (K, F)).astype(np.float32)).to(dev)
+    st, P = _capi.stream_of(dev), _capi.ptr
+    prec = _capi.PREC["f16mx8"]
+    pack = torch.empty(lib.ggcn_weight_pack_bytes(K, F, prec), dtype=torch.uint8, device=dev)
+    _capi.check(lib.ggcn_weight_pack(P(w), F, K, F, prec, 0, P(pack), st), "pack")
+    amax = x.abs().max().reshape(1).contiguous()
+    y = torch.full((M, F), float("nan"), device=dev)
+    _capi.check(lib.ggcn_linear_scaled(P(x), K, P(pack), P(y), F, M, K, F, P(amax), st), "ggcn_linear_scaled")
+    want = x.double().cpu() @ w.double().cpu()
+    err = float((y.double().cpu() - want).abs().max())
+    assert err <= 6e-5 * float(want.abs().max()), (err, float(want.abs().max()))
+    # rows of ordinary size next to the outlier: still ~1e-4 of THEIR scale while the outlier is 50x larger
+    rows = [r for r in range(min(M, 64)) if r != M // 2]
+    err_r = float((y[rows].double().cpu() - want[rows]).abs().max())
+    assert err_r <= 2e-3 * float(want[rows].abs().max())
+    # the plain f16mx8 linear on the same tiny data loses it (that is why the backward used bf16x3): only checked where fp16 flushes
+    if scale < 1e-8:
+        y0 = torch.empty(M, F, device=dev)
+        _capi.check(lib.ggcn_linear(P(x), K, P(w), F, P(pack), P(y0), F, M, K, F, prec, st), "ggcn_linear")
+        assert float((y0.double().cpu() - want).abs().max()) > 100 * err
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        lib.ggcn_range_flag(P(flag), 1, st)
+    inf = torch.full((1,), float("inf"), device=dev)
+    _capi.check(lib.ggcn_linear_scaled(P(x), K, P(pack), P(y), F, M, K, F, P(inf), st), "ggcn_linear_scaled(inf)")
+    torch.cuda.synchronize()
+    assert lib.ggcn_linear_scaled(P(x), K + 1, P(pack), P(y), F, M, K + 1, F, P(amax), st) != 0     # K % 32 != 0: refused
 
 
 @pytest.mark.parametrize("precision,fused", MODES, ids=MODE_IDS)
