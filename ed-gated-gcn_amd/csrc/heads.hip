@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kHeadThreads) void dense_head_kernel(const float *_
                                                                   float *__restrict__ logits, int64_t ldl, const float *__restrict__ part,
                                                                   int n_part, float *__restrict__ xy, int head_blocks)
 {
-    extern __shared__ float head_lds[];   // [kHeadRows][H] pooled rows, then [kHeadWaves][kHeadRows][64] partial sums
+    extern __shared__ __attribute__((aligned(16))) float head_lds[];   // [kHeadRows][H] pooled rows, then [kHeadWaves][kHeadRows][64] partial sums
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int)blockIdx.x >= head_blocks) {   // the regulariser's final sum (one workgroup; fixed order: deterministic)
@@ -186,11 +186,26 @@ __global__ __launch_bounds__(kHeadThreads) void dense_head_kernel(const float *_
     const int kq = (H + kHeadWaves - 1) / kHeadWaves, k0 = wave * kq, k1 = k0 + kq < H ? k0 + kq : H;
     const int c = lane < C ? lane : 0;
     float acc[kHeadRows] = {};
-#pragma unroll 8
-    for (int k = k0; k < k1; ++k) {
-        const float w = Wt[(int64_t)k * ldw + c];
+    if ((H & 3) == 0 && (kq & 3) == 0) {   // four k per step: one 16-byte LDS broadcast read per row instead of four 4-byte ones
+#pragma unroll 4
+        for (int k = k0; k < k1; k += 4) {
+            float w[4];
 #pragma unroll
-        for (int r = 0; r < kHeadRows; ++r) acc[r] = fmaf(rows[r * H + k], w, acc[r]);   // (an LDS broadcast read)
+            for (int q = 0; q < 4; ++q) w[q] = Wt[(int64_t)(k + q) * ldw + c];
+#pragma unroll
+            for (int r = 0; r < kHeadRows; ++r) {
+                const float4 xv = *reinterpret_cast<const float4 *>(rows + r * H + k);
+                acc[r] = fmaf(xv.x, w[0], acc[r]); acc[r] = fmaf(xv.y, w[1], acc[r]);     // (k ascending: the order of the scalar loop)
+                acc[r] = fmaf(xv.z, w[2], acc[r]); acc[r] = fmaf(xv.w, w[3], acc[r]);
+            }
+        }
+    } else {
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) {
+            const float w = Wt[(int64_t)k * ldw + c];
+#pragma unroll
+            for (int r = 0; r < kHeadRows; ++r) acc[r] = fmaf(rows[r * H + k], w, acc[r]);   // (an LDS broadcast read)
+        }
     }
 #pragma unroll
     for (int r = 0; r < kHeadRows; ++r) red[(wave * kHeadRows + r) * 64 + lane] = acc[r];

@@ -1719,7 +1719,8 @@ def test_bench_self_launches_its_ranks_and_the_gathered_logits_match_the_unshard
     assert r["value"] > 0 and "roofline" in r
 
 
-def test_bench_distributed_loop_over_rccl_with_a_process_group_of_one(pkg, dev):
+@pytest.mark.parametrize("gather_mode", ["async", "graph"])
+def test_bench_distributed_loop_over_rccl_with_a_process_group_of_one(pkg, dev, gather_mode):
     """The only collective of the path (BASELINE configs[2]: all-gather of per-shard logits over xGMI) runs on RCCL, and the
     build box has one GPU: `bench.py --gpus 1 --force-dist --backend nccl` runs bench.py's N > 1 step loop -- RCCL process
     group bound to the device (`init_process_group("nccl", device_id=...)`, HSA_ENABLE_IPC_MODE_LEGACY=0), hipGraph replay
