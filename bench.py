@@ -509,8 +509,11 @@ def box_block(pkg, torch, dev, lib, step, sync_all, ms_per_step, block_args_ok):
         cst = torch.zeros(n_wg, 2, dtype=torch.int64, device=dev)
         sink = torch.zeros(256, device=dev)
         call = lambda: _capi.check(lib.ggcn_debug_mfma_calibrate(n_wg, stages, _capi.ptr(cst), _capi.ptr(sink), st), "mfma_calibrate")  # noqa: E731
-        for _ in range(1000):
-            call()
+        with PowerSampler() as ps2:   # what the matrix pipes alone draw: ~0.35 s of back-to-back calibration launches
+            for _ in range(1000):
+                call()
+            torch.cuda.synchronize(dev)
+        pw = ps2.summary()
         ev = []
         for _ in range(100):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -522,6 +525,7 @@ def box_block(pkg, torch, dev, lib, step, sync_all, ms_per_step, block_args_ok):
         # 6144 workgroups x 4 wavefronts x 24 stages x (16 fp16 + 8 fp8-MX MFMAs of 32x32) = the block's main-loop MFMAs:
         # 2 parts x 2*N*K*F algorithmic flops at 128 matrix-pipe cycles per 32^3 block
         box.update({"mfma_calib_us": us, "mfma_calib_clock_mhz": mhz, "mfma_calib_loop_us_per_workgroup": loop_us,
+                    "mfma_calib_power_w": pw.get("power_w"),
                     "mfma_calib_ref_us": MFMA_CALIB_REF_US,
                     "mfma_calib_note": "ggcn_debug_mfma_calibrate(6144 workgroups, 24 stages): the block kernel's main-loop MFMAs at config 2 on random "
                                        "register operands, no memory / LDS traffic, two workgroups per CU; median of 100 launches by HIP events behind 1000 "
