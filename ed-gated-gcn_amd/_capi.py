@@ -58,6 +58,9 @@ PROTOTYPES = {
                                              c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_uint64, c_i32, c_i32, c_i32, c_vp]),
     "ggcn_gate_pool_backward_agg": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                                             c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_uint64, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "ggcn_rowmask_transpose": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "ggcn_gate_pool_backward_mma": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                            c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ggcn_linear_scaled": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_layer_fused_drop": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_vp, c_vp, c_i32, ctypes.c_float, ctypes.c_uint64, c_i32, c_i32, c_i32, c_vp]),

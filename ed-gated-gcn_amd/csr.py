@@ -61,7 +61,7 @@ class BatchedCSR:
     kernel: all the fused layer needs); the CSR arrays are materialised on first access."""
 
     __slots__ = ("_rowptr", "_colidx", "_vals", "rowmask", "B", "T", "nnz", "is_binary",
-                 "_dense", "_dense_version", "_t", "_inv", "_graph_ops", "_graph_ops2", "__weakref__")
+                 "_dense", "_dense_version", "_t", "_inv", "_graph_ops", "_graph_ops2", "_graph_ops_t", "__weakref__")
 
     def __init__(self, rowptr, colidx, vals, B, T, nnz=None, rowmask=None):
         self._rowptr, self._colidx, self._vals, self.rowmask = rowptr, colidx, vals, rowmask
@@ -73,6 +73,7 @@ class BatchedCSR:
         self._inv = None     # cached 1/(rowsum+1) per node
         self._graph_ops = None   # cached ggcn_graph_operands blocks (T <= 32)
         self._graph_ops2 = None  # cached ggcn_graph_operands2 blocks per plane type (the one-launch block)
+        self._graph_ops_t = None  # cached ggcn_graph_operands blocks of the TRANSPOSED row masks (the MFMA backward)
 
     @property
     def graph_ops(self):
@@ -87,6 +88,22 @@ class BatchedCSR:
                                                     _capi.stream_of(dev)), "ggcn_graph_operands")
             self._graph_ops = ops
         return self._graph_ops
+
+    @property
+    def graph_ops_t(self):
+        """``ggcn_graph_operands`` blocks of the transposed adjacency (graphs of <= 32 nodes): the A^T operand of the backward's
+        ``dH = A^T . D . dY`` on the matrix cores (``ggcn_gate_pool_backward_mma``); built from the row masks on first use."""
+        if self._graph_ops_t is None and self.rowmask is not None and self.T <= 32 and self.rowmask.is_cuda:
+            lib = _capi.load_library()
+            dev = self.rowmask.device
+            mt = torch.empty_like(self.rowmask)
+            ops = torch.empty(lib.ggcn_graph_operands_bytes(self.B), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                st = _capi.stream_of(dev)
+                _capi.check(lib.ggcn_rowmask_transpose(_capi.ptr(self.rowmask), self.B, self.T, _capi.ptr(mt), st), "ggcn_rowmask_transpose")
+                _capi.check(lib.ggcn_graph_operands(_capi.ptr(mt), self.B, self.T, _capi.ptr(ops), st), "ggcn_graph_operands")
+            self._graph_ops_t = ops
+        return self._graph_ops_t
 
     def graph_ops2(self, plane):
         """uint8 [B * GGCN_GRAPH_OPS2_BYTES]: the block's second layer as ONE operand per graph -- (D.A)^2 in the plane type

@@ -233,6 +233,20 @@ int ggcn_gate_pool_backward_agg(const float *out, int64_t ldo, const float *stor
                                   d_ga, d_gb, d_bsum, as_stream(stream), p > 0.0f ? &d : nullptr, dh_amax);
 }
 
+int ggcn_rowmask_transpose(const uint32_t *rowmask, int B, int T, uint32_t *rowmask_t, ggcn_stream_t stream)
+{
+    return rowmask_transpose(rowmask, B, T, rowmask_t, as_stream(stream));
+}
+
+int ggcn_gate_pool_backward_mma(const float *out, int64_t ldo, const float *store_gate, const float *gate_a, const float *gate_b,
+                                const float *d_out, int64_t ldd, const float *d_pa, const float *d_pb, const void *graph_ops,
+                                const void *graph_ops_t, int B, int T, int F, float *dH, int64_t ldh, float *d_sg, float *d_ga,
+                                float *d_gb, float *d_bsum, float *dh_amax, ggcn_stream_t stream)
+{
+    return gate_pool_backward_mma(out, ldo, store_gate, gate_a, gate_b, d_out, ldd, d_pa, d_pb, graph_ops, graph_ops_t, B, T, F, dH, ldh,
+                                  d_sg, d_ga, d_gb, d_bsum, dh_amax, as_stream(stream));
+}
+
 int ggcn_linear_scaled(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy, int64_t M, int K, int F,
                        const float *amax, ggcn_stream_t stream)
 {

@@ -97,6 +97,11 @@ int gate_pool_backward_agg(const float *out, int64_t ldo, const float *store_gat
                            const float *d_pb, const uint32_t *rowmask, int B, int T, int F, float *dH, int64_t ldh,
                            float *d_sg, float *d_ga, float *d_gb, float *d_bsum, hipStream_t st, const struct DropSpec *drop = nullptr,
                            float *dh_amax = nullptr);
+int rowmask_transpose(const uint32_t *rowmask, int B, int T, uint32_t *rowmask_t, hipStream_t st);   // gate_pool_backward_mma.hip
+int gate_pool_backward_mma(const float *out, int64_t ldo, const float *store_gate, const float *gate_a, const float *gate_b,
+                           const float *d_out, int64_t ldd, const float *d_pa, const float *d_pb, const void *graph_ops,
+                           const void *graph_ops_t, int B, int T, int F, float *dH, int64_t ldh, float *d_sg, float *d_ga,
+                           float *d_gb, float *d_bsum, float *dh_amax, hipStream_t st);
 size_t colsum_workspace_bytes(int F);
 int colsum(const float *X, int64_t ld, int64_t M, int F, float *out, void *workspace, hipStream_t st);
 

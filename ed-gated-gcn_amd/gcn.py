@@ -90,10 +90,19 @@ class _GatedLayerFunction(torch.autograd.Function):
             # dX on the two-unit f16mx8 product (ggcn_linear_scaled): the launch that makes dH also leaves max |dH|, from which the
             # linear derives a power-of-two scale on the device -- gradients have no range contract of their own
             dx = None
-            scaled_dx = (one_pass and need[0] and layer.precision == "f16mx8" and K % 4 == 0 and F % 256 == 0
+            scaled_dx = (one_pass and need[0] and layer.precision == "f16mx8" and K % 4 == 0 and (F % 256 == 0 or ctx.dropout is None)
                          and os.environ.get("GGCN_DX_PRECISION", "f16mx8") == "f16mx8")
             dh_amax = torch.zeros(1, dtype=torch.float32, device=dev) if scaled_dx else None
-            if one_pass:
+            # ... and without gate dropout on the matrix cores: dH_g = A_g^T . (D.dY_g) as an MFMA chain (ggcn_gate_pool_backward_mma)
+            mma = (one_pass and ctx.dropout is None and os.environ.get("GGCN_BACKWARD_SCALAR", "0") != "1"
+                   and csr.graph_ops is not None and csr.graph_ops_t is not None)
+            if mma:
+                _capi.check(lib.ggcn_gate_pool_backward_mma(
+                    _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),
+                    _capi.ptr(d_out2), F, _capi.ptr(d_pa), _capi.ptr(d_pb), _capi.ptr(csr.graph_ops), _capi.ptr(csr.graph_ops_t), B, T, F,
+                    _capi.ptr(dh), F, _capi.ptr(d_sg), _capi.ptr(d_ga), _capi.ptr(d_gb), _capi.ptr(d_bsum), _capi.ptr(dh_amax), st),
+                    "ggcn_gate_pool_backward_mma")
+            elif one_pass:
                 dp, dseed, (ss, sa, sb) = ctx.dropout if ctx.dropout is not None else (0.0, 0, (0, 0, 0))
                 _capi.check(lib.ggcn_gate_pool_backward_agg(
                     _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),

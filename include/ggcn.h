@@ -233,6 +233,17 @@ int ggcn_gate_pool_backward_agg(const float *out, int64_t ldo, const float *stor
  *   A non-finite amax leaves the data unscaled (the result is non-finite either way). */
 int ggcn_linear_scaled(const float *X, int64_t ldx, const void *wpack, float *Y, int64_t ldy, int64_t M, int K, int F,
                        const float *amax, ggcn_stream_t stream);
+/* The same two steps on the matrix cores (no gate dropout): dH_g = A_g^T . (D.dY_g) as one MFMA chain per (graph, 32 columns)
+ * -- D.dY split into three bf16 planes (2^-25 of its scale), A^T an exact 0/1 operand -- instead of 1024 scalar bit tests per
+ * thread.  graph_ops: the graph's ggcn_graph_operands blocks (their 1/(rowsum+1) table); graph_ops_t: ggcn_graph_operands blocks of
+ * the TRANSPOSED row masks (ggcn_rowmask_transpose: bit t of word s = bit s of word t; once per adjacency tensor).  Same results as
+ * ggcn_gate_pool_backward_agg up to the order of additions (gate gradients and bias sums: two partial sums per column instead of one
+ * sequential sum; arg-max ties go to the smaller row in both).  Needs F % 4 == 0, ldh % 4 == 0, 16-byte aligned dH. */
+int ggcn_rowmask_transpose(const uint32_t *rowmask, int B, int T, uint32_t *rowmask_t, ggcn_stream_t stream);
+int ggcn_gate_pool_backward_mma(const float *out, int64_t ldo, const float *store_gate, const float *gate_a,
+                                const float *gate_b, const float *d_out, int64_t ldd, const float *d_pa, const float *d_pb,
+                                const void *graph_ops, const void *graph_ops_t, int B, int T, int F, float *dH, int64_t ldh,
+                                float *d_sg, float *d_ga, float *d_gb, float *d_bsum, float *dh_amax, ggcn_stream_t stream);
 /* d_bsum (NULL or [B,F]) receives sum_t dY per graph; db = sum_rows dY is then ggcn_colsum over its B rows.
  * ggcn_colsum: out[f] = sum_r X[r,f] for X [M, ld], deterministic (fixed-order slab sums);
  * workspace: ggcn_colsum_workspace_bytes(F) bytes. */

@@ -542,6 +542,88 @@ def test_gate_pool_backward_with_the_transposed_aggregation_in_one_launch(pkg, d
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T,F,directed", [(7, 32, 256, False), (5, 17, 20, True), (3, 31, 1028, True), (64, 32, 768, False), (1, 1, 8, False), (9, 32, 64, True)])
+def test_gate_pool_backward_on_the_matrix_cores(pkg, dev, B, T, F, directed):
+    """ggcn_gate_pool_backward_mma: dH_g = A_g^T . (D.dY_g) as an MFMA chain per (graph, 32 columns) against the scalar one-launch
+    form (ggcn_gate_pool_backward_agg) and a float64 statement -- DIRECTED graphs too (A^T is not A: the operand comes from the
+    transposed row masks), ragged lengths, negative gates, dead columns past F, a one-node graph, absent optional operands;
+    max |dH| rides along; what it must refuse."""
+    from ed_gated_gcn_amd import _capi, synth
+    lib = pkg.load_library()
+    rng = np.random.default_rng(B * 100 + T + F)
+    lens = rng.integers(1, T + 1, size=B)
+    adj = synth.dependency_batch(B, T, min(4.0, T), seed=3, lengths=lens).astype(np.float32)
+    if directed:   # drop a random half of the arcs' reverse directions (self loops stay)
+        keep = rng.random(adj.shape) < 0.5
+        adj = np.where(np.triu(np.ones((T, T), bool), 1)[None] & keep, 0.0, adj).astype(np.float32)
+    csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj).to(dev))
+    assert csr.is_binary and csr.graph_ops is not None and csr.graph_ops_t is not None
+    # the transposed masks really are the transpose
+    mt = torch.empty_like(csr.rowmask)
+    _capi.check(lib.ggcn_rowmask_transpose(_capi.ptr(csr.rowmask), B, T, _capi.ptr(mt), _capi.stream_of(dev)), "transpose")
+    bits = ((mt.view(B, T).cpu().numpy().astype(np.int64)[:, :, None] >> np.arange(T)[None, None, :]) & 1).astype(np.float32)
+    np.testing.assert_array_equal(bits, np.transpose(adj, (0, 2, 1)))
+    out = torch.from_numpy(rng.standard_normal((B * T, F)).astype(np.float32)).to(dev)
+    sg = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32))).to(dev)
+    ga = torch.from_numpy(rng.uniform(-1.0, 1.0, (B, F)).astype(np.float32)).to(dev)
+    gb = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32))).to(dev)
+    d_out = torch.from_numpy(rng.standard_normal((B * T, F)).astype(np.float32)).to(dev)
+    d_pa = torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32)).to(dev)
+    d_pb = torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32)).to(dev)
+    p, st = _capi.ptr, _capi.stream_of(dev)
+
+    def outs():
+        return [torch.full((B, F), float("nan"), device=dev) for _ in range(4)]
+
+    def run_mma(sg_, ga_, gb_, do_, pa_, pb_, with_amax=True):
+        dh = torch.full((B * T, F), float("nan"), device=dev)
+        o = outs()
+        amax = torch.zeros(1, device=dev) if with_amax else None
+        _capi.check(lib.ggcn_gate_pool_backward_mma(p(out), F, p(sg_), p(ga_), p(gb_), p(do_), F, p(pa_), p(pb_), p(csr.graph_ops), p(csr.graph_ops_t),
+                                                    B, T, F, p(dh), F, p(o[0]) if sg_ is not None else None, p(o[1]) if pa_ is not None else None,
+                                                    p(o[2]) if pb_ is not None else None, p(o[3]), p(amax), st), "ggcn_gate_pool_backward_mma")
+        return dh, o, amax
+
+    def run_ref(sg_, ga_, gb_, do_, pa_, pb_):
+        dh = torch.full((B * T, F), float("nan"), device=dev)
+        o = outs()
+        _capi.check(lib.ggcn_gate_pool_backward_agg(p(out), F, p(sg_), p(ga_), p(gb_), p(do_), F, p(pa_), p(pb_), p(csr.rowmask), B, T, F, p(dh), F,
+                                                    p(o[0]) if sg_ is not None else None, p(o[1]) if pa_ is not None else None,
+                                                    p(o[2]) if pb_ is not None else None, p(o[3]), 0.0, 0, 0, 0, 0, None, st), "ggcn_gate_pool_backward_agg")
+        return dh, o
+
+    if F % 4 != 0:
+        return
+    for case in ((sg, ga, gb, d_out, d_pa, d_pb), (None, ga, None, None, d_pa, None), (sg, None, gb, d_out, None, d_pb)):
+        dh, o, amax = run_mma(*case)
+        dh_ref, o_ref = run_ref(*case)
+        scale = float(dh_ref.abs().max()) + 1e-30
+        assert bool(torch.isfinite(dh).all())
+        assert float((dh - dh_ref).abs().max()) <= 4e-7 * scale, float((dh - dh_ref).abs().max()) / scale
+        assert float(amax) == float(dh.abs().max())
+        for name, u, v, used in (("d_sg", o[0], o_ref[0], case[0] is not None), ("d_ga", o[1], o_ref[1], case[4] is not None),
+                                 ("d_gb", o[2], o_ref[2], case[5] is not None), ("d_bsum", o[3], o_ref[3], True)):
+            if used:
+                assert float((u - v).abs().max()) <= 2e-6 * (float(v.abs().max()) + 1e-30), name
+    # float64 statement for the full case: dH[s] = sum_t A[t,s] dY[t] / (deg_t + 1), dY from the scalar two-call kernel
+    dy = torch.empty(B * T, F, device=dev)
+    r = outs()
+    _capi.check(lib.ggcn_gate_pool_backward(p(out), F, p(sg), p(ga), p(gb), p(d_out), F, p(d_pa), p(d_pb), B, T, F, p(dy), F,
+                                            p(r[0]), p(r[1]), p(r[2]), p(r[3]), st), "ggcn_gate_pool_backward")
+    a64 = torch.from_numpy(adj).double()
+    w64 = 1.0 / (a64.sum(2) + 1.0)
+    want = torch.einsum("bts,btf->bsf", a64 * w64[:, :, None], dy.view(B, T, F).double().cpu())
+    dh, o, _ = run_mma(sg, ga, gb, d_out, d_pa, d_pb, with_amax=False)
+    assert float((dh.view(B, T, F).double().cpu() - want).abs().max()) <= 2e-6 * (float(want.abs().max()) + 1e-30)
+    assert torch.equal(o[1], r[1]) and torch.equal(o[2], r[2])      # d_ga, d_gb: the same winners, the same products
+    # refusals
+    assert lib.ggcn_gate_pool_backward_mma(p(out), F, None, None, None, p(d_out), F, None, None, p(csr.graph_ops), p(csr.graph_ops_t), 1, 33, F,
+                                           p(dh), F, None, None, None, None, None, st) != 0
+    assert lib.ggcn_gate_pool_backward_mma(p(out), F, None, None, None, p(d_out), F, None, None, p(csr.graph_ops), None, B, T, F,
+                                           p(dh), F, None, None, None, None, None, st) != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,K,F,scale", [(4096, 768, 768, 1.0), (300, 96, 64, 3.0e-9), (1000, 256, 128, 2.0e7), (128, 32, 4, 1.0e-30)])
 def test_scaled_f16mx8_linear_for_gradients_of_any_magnitude(pkg, dev, M, K, F, scale):
     """ggcn_linear_scaled (the backward's dX = dH . W^T, train.py:120): the two-unit f16mx8 product on rows far outside fp16's
