@@ -139,6 +139,31 @@ def time_variants(what, names):
         if ref is None:
             ref = res
         print("%-24s max|diff vs %s| = %.3g" % (n, names[0], float((res - ref).abs().max())))
+    if os.environ.get("LAB_ENERGY"):   # each variant alone for ~1.5 s: board power from sysfs beside it (bench.py's sampler) -> energy per launch
+        sys.path.insert(0, ROOT)
+        import bench
+        import time as _time
+        for n in names:
+            for _ in range(300):
+                run(n)
+            torch.cuda.synchronize()
+            with bench.PowerSampler() as ps:
+                a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t_end = _time.perf_counter() + 1.5
+                cnt = 0
+                a.record()
+                while _time.perf_counter() < t_end:
+                    for _ in range(100):
+                        run(n)
+                    cnt += 100
+                    torch.cuda.synchronize()
+                e.record()
+                torch.cuda.synchronize()
+            us = a.elapsed_time(e) / cnt * 1e3
+            pw = ps.summary()
+            print("%-10s %8.1f us per launch   %7.1f W (max %7.1f, sclk %s MHz)   %.4f J per launch" %
+                  (n, us, pw.get("power_w") or float("nan"), pw.get("power_w_max") or float("nan"), pw.get("sclk_dpm_mhz"), us * 1e-6 * (pw.get("power_w") or float("nan"))), flush=True)
+        return
     for _ in range(150):          # precondition: the chip needs ~50 ms of load to settle
         run(names[0])
     torch.cuda.synchronize()
