@@ -90,12 +90,14 @@ class _GatedLayerFunction(torch.autograd.Function):
             # dX on the two-unit f16mx8 product (ggcn_linear_scaled): the launch that makes dH also leaves max |dH|, from which the
             # linear derives a power-of-two scale on the device -- gradients have no range contract of their own
             dx = None
-            scaled_dx = (one_pass and need[0] and layer.precision == "f16mx8" and K % 4 == 0 and (F % 256 == 0 or ctx.dropout is None)
-                         and os.environ.get("GGCN_DX_PRECISION", "f16mx8") == "f16mx8")
-            dh_amax = torch.zeros(1, dtype=torch.float32, device=dev) if scaled_dx else None
-            # ... and without gate dropout on the matrix cores: dH_g = A_g^T . (D.dY_g) as an MFMA chain (ggcn_gate_pool_backward_mma)
+            # without gate dropout the backward runs on the matrix cores: dH_g = A_g^T . (D.dY_g) as an MFMA chain (ggcn_gate_pool_backward_mma)
             mma = (one_pass and ctx.dropout is None and os.environ.get("GGCN_BACKWARD_SCALAR", "0") != "1"
                    and csr.graph_ops is not None and csr.graph_ops_t is not None)
+            # (the scaled linear wants its reduction length F % 32 == 0 and 16-byte rows; the scalar launch hands max |dH| over for
+            # whole wavefronts of columns only)
+            scaled_dx = (one_pass and need[0] and layer.precision == "f16mx8" and K % 4 == 0 and F % 32 == 0 and (mma or F % 256 == 0)
+                         and os.environ.get("GGCN_DX_PRECISION", "f16mx8") == "f16mx8")
+            dh_amax = torch.zeros(1, dtype=torch.float32, device=dev) if scaled_dx else None
             if mma:
                 _capi.check(lib.ggcn_gate_pool_backward_mma(
                     _capi.ptr(out2), F, _capi.ptr(store_gate), _capi.ptr(gate_a), _capi.ptr(gate_b),

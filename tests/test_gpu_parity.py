@@ -445,7 +445,7 @@ def _grad_close(got, want, name, rel=2e-4):
 
 
 @pytest.mark.parametrize("precision,fused", MODES, ids=MODE_IDS)
-@pytest.mark.parametrize("B,T,K,F,weighted", [(8, 32, 256, 256, False), (3, 100, 64, 48, True), (5, 17, 34, 20, False)])
+@pytest.mark.parametrize("B,T,K,F,weighted", [(8, 32, 256, 256, False), (3, 100, 64, 48, True), (5, 17, 34, 20, False), (6, 20, 64, 96, False)])
 def test_layer_backward_vs_oracle_autograd(pkg, dev, precision, fused, B, T, K, F, weighted):
     """train.py:115-121 trains through gc1/gc2: gradients of the HIP layer (transposed-CSR
     aggregation + MFMA dX + library dW) against torch autograd on the oracle's dense forward."""
