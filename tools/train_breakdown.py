@@ -35,3 +35,14 @@ with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) a
         r = pkg.gated_gcn_block(xx, csr, g1, g2, *ls); (r["out"].sum() + 0.01 * r["xy"]).backward()
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=60))
+# steady state: the step alone (setup, packs and operand blocks exist), HIP events around forward + backward, median of 10 behind 3 untimed
+def train_step():
+    for m in ls:
+        m.weight.grad = None; m.bias.grad = None
+    xx.grad = None; g1.grad = None; g2.grad = None
+    r = pkg.gated_gcn_block(xx, csr, g1, g2, *ls); (r["out"].sum() + 0.01 * r["xy"]).backward()
+print("steady-state training step (forward + backward of the block, loss = out.sum() + 0.01 xy): %.1f us" % timeit(train_step, n=10))
+def fwd_only():
+    with torch.no_grad():
+        pkg.gated_gcn_block(xx, csr, g1, g2, *ls, one_launch=False)
+print("the two one-launch layers alone (what the training forward runs): %.1f us" % timeit(fwd_only, n=10))
