@@ -24,6 +24,8 @@ PROTOTYPES = {
     "ggcn_rowmask_from_dense": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "ggcn_csr_transpose": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ggcn_csr_rowmask": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "ggcn_graph_edge_lists_bytes": (c_sz, [c_i32]),
+    "ggcn_graph_edge_lists": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_graph_operands_bytes": (c_sz, [c_i32]),
     "ggcn_graph_operands": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "ggcn_graph_operands2_bytes": (c_sz, [c_i32]),

@@ -61,7 +61,7 @@ class BatchedCSR:
     kernel: all the fused layer needs); the CSR arrays are materialised on first access."""
 
     __slots__ = ("_rowptr", "_colidx", "_vals", "rowmask", "B", "T", "nnz", "is_binary",
-                 "_dense", "_dense_version", "_t", "_inv", "_graph_ops", "_graph_ops2", "_graph_ops_t", "__weakref__")
+                 "_dense", "_dense_version", "_t", "_inv", "_graph_ops", "_graph_ops2", "_graph_ops_t", "_edge_lists", "__weakref__")
 
     def __init__(self, rowptr, colidx, vals, B, T, nnz=None, rowmask=None):
         self._rowptr, self._colidx, self._vals, self.rowmask = rowptr, colidx, vals, rowmask
@@ -74,6 +74,7 @@ class BatchedCSR:
         self._graph_ops = None   # cached ggcn_graph_operands blocks (T <= 32)
         self._graph_ops2 = None  # cached ggcn_graph_operands2 blocks per plane type (the one-launch block)
         self._graph_ops_t = None  # cached ggcn_graph_operands blocks of the TRANSPOSED row masks (the MFMA backward)
+        self._edge_lists = None   # cached ggcn_graph_edge_lists blocks (graphs of 129..256 nodes: the eight-wavefront layer)
 
     @property
     def graph_ops(self):
@@ -88,6 +89,20 @@ class BatchedCSR:
                                                     _capi.stream_of(dev)), "ggcn_graph_operands")
             self._graph_ops = ops
         return self._graph_ops
+
+    @property
+    def edge_lists(self):
+        """``ggcn_graph_edge_lists`` blocks (graphs of 129..256 nodes with row masks) or None: the per-row edge lists the
+        eight-wavefront one-launch layer walks, made once per adjacency tensor instead of by every workgroup of every launch."""
+        if self._edge_lists is None and self.rowmask is not None and 128 < self.T <= 256 and self.rowmask.is_cuda:
+            lib = _capi.load_library()
+            dev = self.rowmask.device
+            lists = torch.empty(lib.ggcn_graph_edge_lists_bytes(self.B), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _capi.check(lib.ggcn_graph_edge_lists(_capi.ptr(self.rowmask), self.B, self.T, _capi.ptr(lists), _capi.stream_of(dev)),
+                            "ggcn_graph_edge_lists")
+            self._edge_lists = lists
+        return self._edge_lists
 
     @property
     def graph_ops_t(self):

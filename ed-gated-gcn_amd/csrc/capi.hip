@@ -78,6 +78,13 @@ int ggcn_graph_operands2(const uint32_t *rowmask, int B, int T, int plane, void 
     return graph_operands2(rowmask, B, T, plane, graph_ops2, as_stream(stream));
 }
 
+size_t ggcn_graph_edge_lists_bytes(int B) { return B > 0 ? (size_t)B * GGCN_EDGE_LISTS_BYTES : 0; }
+
+int ggcn_graph_edge_lists(const uint32_t *rowmask, int B, int T, void *lists, ggcn_stream_t stream)
+{
+    return graph_edge_lists(rowmask, B, T, lists, as_stream(stream));
+}
+
 int ggcn_graph_operands(const uint32_t *rowmask, int B, int T, void *graph_ops, ggcn_stream_t stream)
 {
     return graph_operands(rowmask, B, T, graph_ops, as_stream(stream));

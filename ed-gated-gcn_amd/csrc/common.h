@@ -72,6 +72,7 @@ int subword_pool(const float *A, int64_t sa_b, int64_t sa_r, int64_t sa_c, const
                  int64_t ldx, float *Y, int64_t y_batch, int64_t ldy, int B, int R, int C, int D, hipStream_t st);
 int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint32_t *rowmask, hipStream_t st);
 int graph_operands(const uint32_t *rowmask, int B, int T, void *ops, hipStream_t st);
+int graph_edge_lists(const uint32_t *rowmask, int B, int T, void *lists, hipStream_t st);   // fused_wide8.hip
 int graph_operands2(const uint32_t *rowmask, int B, int T, int plane, void *ops2, hipStream_t st);
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops, const float *bias,
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,

@@ -322,6 +322,7 @@ int launch_fused(const char *who, FusedArgs &a, int precision, hipStream_t st)
         return fail(GGCN_EINVAL, "%s: graphs of %d nodes need %s", who, a.T,
                     a.T > 32 ? "the row masks" : "the per-graph operand blocks of ggcn_graph_operands");
     if (a.T <= 32 && !aligned16(a.graph_ops)) return fail(GGCN_EINVAL, "%s: graph_ops must be 16-byte aligned", who);
+    if (a.T > 128 && a.graph_ops && !aligned16(a.graph_ops)) return fail(GGCN_EINVAL, "%s: the edge-list blocks must be 16-byte aligned", who);
     if (a.B <= 0 || a.T <= 0 || a.K <= 0 || a.F <= 0)
         return fail(GGCN_EINVAL, "%s: B=%d T=%d K=%d F=%d must be positive", who, a.B, a.T, a.K, a.F);
     if (a.T > GGCN_MASK_MAX_T)

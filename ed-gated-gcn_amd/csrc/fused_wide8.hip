@@ -27,6 +27,8 @@ constexpr int kW8Ex = 8 * 16 * 1024;          // per wavefront: 4 row blocks x (
 constexpr int kW8Cap = 16;                   // source ids per row kept in LDS (rows with more neighbours walk their mask words)
 constexpr int kW8Stage = 4096;                // per wavefront: 32 rows x 32 columns of output on their way to 16-byte stores
 constexpr int kW8Lds = kW8Ex + 8 * kW8Stage;  // 160 KiB
+constexpr int kW8ListBytes = GGCN_EDGE_LISTS_BYTES;   // ids 8192 + degrees 1024 + reciprocals 1024 + zero row 128, padded to 11 KiB
+static_assert(4096 + kW8ListBytes <= 8 * kW8Stage, "the lists' LDS image lies behind both row groups' stage buffers");
 static_assert(2 * kLdsBytes <= kW8Ex && kW8Lds <= 160 * 1024, "the stage buffers of both row groups lie under the exchange area");
 
 // DROP (training, bert_amir5.py:621-625): per-(token, feature) keep factors of the three gates (dropout_hash.h), the pools
@@ -69,6 +71,15 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
     // lies behind both row groups' stage buffers, and the row masks' trip from global memory hides under the loop's first
     // stages instead of standing between the loop and the epilogue ----
     if constexpr (!GGCN_LAB_WIDE8_DENSE) {
+      if (a.graph_ops) {
+          // ggcn_graph_edge_lists made the lists once per adjacency tensor: the block IS the LDS image (ids, degrees, reciprocals, the
+          // zero row), 11 pieces of 1 KiB brought in by LDS-DMA -- no registers, no instructions beyond the 1-2 issues per wavefront;
+          // they land under the main loop's first stages (its per-stage vmcnt(0) + barrier cover them long before the epilogue)
+          const char *blk = a.graph_ops + (int64_t)g * kW8ListBytes;
+          for (int piece = wave; piece < kW8ListBytes / 1024; piece += 8)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + piece * 1024 + lane * 16),
+                                               (__attribute__((address_space(3))) void *)(lds8 + kW8Ex + 4096 + piece * 1024), 16, 0, 0);
+      } else {
         unsigned short *s_ids = reinterpret_cast<unsigned short *>(lds8 + kW8Ex + 4096);   // [256 rows][kW8Cap]
         int *s_deg = reinterpret_cast<int *>(lds8 + kW8Ex + 4096 + 256 * kW8Cap * 2);      // [256]
         float *s_inv = reinterpret_cast<float *>(lds8 + kW8Ex + 4096 + 256 * kW8Cap * 2 + 1024);   // [256] 1 / (deg + 1)
@@ -101,6 +112,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
             s_inv[row] = 1.0f / (float)(deg + 1);                               // gcn.py:35
             if (tid < 32) reinterpret_cast<float *>(lds8 + zero_off)[tid] = 0.0f;
         }
+      }
     }
 
     // ---- hidden = X . W for both row groups at once ----
@@ -553,6 +565,46 @@ __global__ __launch_bounds__(kW8Threads, 2) void layer_fused_wide8_kernel(const 
 }
 
 
+// ggcn_graph_edge_lists: per graph of 129..256 nodes the LDS image the eight-wavefront kernel's neighbour sums read -- per row up to
+// kW8Cap source rows as byte offsets into an fp32 tile [256][32] (its chunk swizzle included), the degree and 1 / (deg + 1)
+// (gcn.py:35), a zero row -- made ONCE per adjacency tensor instead of by every (graph, 256 columns) workgroup of every launch.
+__global__ __launch_bounds__(256) void graph_edge_lists_kernel(const uint32_t *__restrict__ rowmask, int T, char *__restrict__ lists)
+{
+    const int g = blockIdx.x, row = threadIdx.x;
+    const int W = (T + 31) >> 5;
+    char *blk = lists + (int64_t)g * kW8ListBytes;
+    unsigned short *ids = reinterpret_cast<unsigned short *>(blk);
+    int *deg_o = reinterpret_cast<int *>(blk + 256 * kW8Cap * 2);
+    float *inv_o = reinterpret_cast<float *>(blk + 256 * kW8Cap * 2 + 1024);
+    auto tile_off = [](int r, int chunk) { return r * 128 + ((chunk ^ (((r >> 1) & 1) << 2)) << 4); };
+    int deg = 0, e = 0;
+    for (int wi = 0; wi < 8; ++wi) {
+        uint32_t w = (row < T && wi < W) ? rowmask[((int64_t)g * T + row) * W + wi] : 0u;
+        deg += __popc(w);
+        while (w && e < kW8Cap) {
+            ids[row * kW8Cap + e++] = (unsigned short)tile_off(32 * wi + __builtin_ctz(w), 0);
+            w &= w - 1;
+        }
+    }
+    for (; e < kW8Cap; ++e) ids[row * kW8Cap + e] = (unsigned short)tile_off(255, 0);
+    deg_o[row] = deg;
+    inv_o[row] = 1.0f / (float)(deg + 1);
+    // the zero row and the padding behind it
+    for (int i = row; i < (kW8ListBytes - (256 * kW8Cap * 2 + 2048)) / 4; i += 256) reinterpret_cast<float *>(blk + 256 * kW8Cap * 2 + 2048)[i] = 0.0f;
+}
+
+}  // namespace
+
+int graph_edge_lists(const uint32_t *rowmask, int B, int T, void *lists, hipStream_t st)
+{
+    if (!rowmask || !lists) return fail(GGCN_EINVAL, "ggcn_graph_edge_lists: null pointer");
+    if (B <= 0 || T <= 128 || T > 256) return fail(GGCN_EUNSUPPORTED, "ggcn_graph_edge_lists: B=%d T=%d (graphs of 129..256 nodes: the eight-wavefront layer)", B, T);
+    if (!aligned16(lists)) return fail(GGCN_EINVAL, "ggcn_graph_edge_lists: lists must be 16-byte aligned");
+    hipLaunchKernelGGL(graph_edge_lists_kernel, dim3((unsigned)B), dim3(256), 0, st, rowmask, T, static_cast<char *>(lists));
+    return check_launch("ggcn_graph_edge_lists");
+}
+
+namespace {
 }  // namespace
 
 int launch_fused_wide8(const char *who, const FusedArgs &a, int precision, bool fast, bool vst, int64_t gridw, hipStream_t st)

@@ -476,7 +476,7 @@ class GraphConvolution(nn.Module):
                 kprec = self.kernel_precision(x2d, csr)
                 pack = self._packed_weight(lib, st, precision=kprec)
                 _capi.check(lib.ggcn_layer_fused(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack),
-                                                 _capi.ptr(csr.rowmask), _capi.ptr(csr.graph_ops), _capi.ptr(bias), B, T,
+                                                 _capi.ptr(csr.rowmask), _capi.ptr(csr.graph_ops if csr.T <= 32 else (csr.edge_lists if os.environ.get("GGCN_EDGE_LISTS", "1") != "0" else None)), _capi.ptr(bias), B, T,
                                                  self.in_features, F, _capi.ptr(store_gate),
                                                  _capi.ptr(pool_gate_a), _capi.ptr(pool_gate_b), _capi.ptr(out),
                                                  F, _capi.ptr(pa), _capi.ptr(pb), _capi.ptr(overlap_partial),

@@ -133,6 +133,14 @@ int ggcn_csr_transpose(const int32_t *rowptr, const int32_t *colidx, const float
  * epilogue multiplies by 2^-10), two k-steps each, plus rowsum(D.A) per row (the factor of the `mid` bias):
  * GGCN_GRAPH_OPS2_BYTES per graph.  ggcn_block_fused reads it for its W12 column tiles. */
 #define GGCN_GRAPH_OPS2_BYTES 4224
+/* Graphs of 129..256 nodes (the eight-wavefront one-launch layer): the neighbour sums walk per-row EDGE LISTS.  ggcn_graph_edge_lists
+ * makes them once per adjacency tensor from the row masks -- per graph GGCN_EDGE_LISTS_BYTES = the kernel's LDS image: per row up to
+ * 16 source rows as byte offsets into its fp32 tile, the degree, 1/(rowsum+1) (models/gcn.py:35), a zero row -- and
+ * ggcn_layer_fused takes the blocks in its graph_ops argument (NULL: every (graph, 256 columns) workgroup builds its lists itself,
+ * as before; rows with more than 16 neighbours walk their mask words either way, so the row masks stay required). */
+#define GGCN_EDGE_LISTS_BYTES 11264
+size_t ggcn_graph_edge_lists_bytes(int B);
+int ggcn_graph_edge_lists(const uint32_t *rowmask, int B, int T, void *lists, ggcn_stream_t stream);
 size_t ggcn_graph_operands_bytes(int B);
 int ggcn_graph_operands(const uint32_t *rowmask, int B, int T, void *graph_ops, ggcn_stream_t stream);
 size_t ggcn_graph_operands2_bytes(int B);

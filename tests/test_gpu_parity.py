@@ -1692,6 +1692,48 @@ def test_dense_head_rides_with_the_regularisers_final_sum(pkg, dev, B, T, H, C):
         pkg.gated_gcn_block(xg, adj, g1, g2, l1, l2, dense_head=(wt, bias))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,F", [(5, 231, 256), (3, 129, 128), (2, 256, 64), (4, 200, 256)])
+def test_precomputed_edge_lists_of_the_eight_wavefront_layer(pkg, dev, B, T, F):
+    """ggcn_graph_edge_lists: the per-row edge lists of graphs of 129..256 nodes made once per adjacency tensor (the kernel's LDS
+    image, brought in by LDS-DMA) instead of by every workgroup -- the same launch with and without them is bit-identical,
+    dense rows (more than 16 neighbours: they walk their mask words either way) and a full 256-node slot included; the blocks
+    hold what a host loop over the dense adjacency says."""
+    from ed_gated_gcn_amd import _capi, synth
+    lib = pkg.load_library()
+    rng = np.random.default_rng(T + F)
+    lens = rng.integers(T // 2, T + 1, size=B); lens[0] = T
+    adj = synth.dependency_batch(B, T, 4.0, seed=4, lengths=lens)
+    adj[0, 3, :40] = 1; adj[0, :40, 3] = 1            # a hub: 40 neighbours, beyond the 16 a list holds
+    csr = pkg.BatchedCSR.from_dense(torch.from_numpy(adj.astype(np.float32)).to(dev))
+    lists = csr.edge_lists
+    assert lists is not None and lists.numel() == B * 11264
+    blk = lists.view(B, 11264).cpu().numpy()
+    deg = blk[:, 8192:9216].copy().view(np.int32); inv = blk[:, 9216:10240].copy().view(np.float32)
+    want_deg = np.zeros((B, 256), np.int32); want_deg[:, :T] = adj.sum(2).astype(np.int32)
+    np.testing.assert_array_equal(deg, want_deg)
+    np.testing.assert_array_equal(inv, (1.0 / (want_deg + 1)).astype(np.float32))
+    assert not blk[:, 10240:10368].any()
+    ids = blk[:, :8192].copy().view(np.uint16).reshape(B, 256, 16)
+    first = [int(np.flatnonzero(adj[1, 5])[e]) for e in range(min(16, int(adj[1, 5].sum())))]
+    assert [int(v) >> 7 for v in ids[1, 5, :len(first)]] == first      # (offset = row * 128 + a chunk flip below 128)
+    x = torch.from_numpy(rng.standard_normal((B * T, 64)).astype(np.float32)).to(dev)
+    w, b = synth.layer_params(64, F, seed=1)
+    m = _layer(pkg, dev, w, b, "f16mx8")
+    st, P = _capi.stream_of(dev), _capi.ptr
+    pack = m._packed_weight(lib, st)
+    g = torch.rand(B, F, device=dev)
+    res = []
+    for ops in (None, lists):
+        out = torch.full((B * T, F), float("nan"), device=dev); pa = torch.empty(B, F, device=dev); pb = torch.empty(B, F, device=dev)
+        _capi.check(lib.ggcn_layer_fused(P(x), 64, P(pack), P(csr.rowmask), P(ops), P(m.bias.detach()), B, T, 64, F, P(g), P(g), None,
+                                         P(out), F, P(pa), P(pb), None, None, None, _capi.PREC["f16mx8"], st), "ggcn_layer_fused")
+        res.append((out, pa))
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and bool(torch.isfinite(res[1][0]).all())
+    assert lib.ggcn_graph_edge_lists(P(csr.rowmask), B, 100, P(lists), st) != 0      # 33..128 nodes: another kernel, no lists
+
+
 # ---------------------------------------------------------------- N > 1 product path on one device (SURVEY 8e)
 def _shard_worker(rank, world, port, ret):
     import traceback
