@@ -44,6 +44,8 @@ PROTOTYPES = {
     "ggcn_absmax": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "ggcn_range_flag": (c_i32, [c_vp, c_i32, c_vp]),
     "ggcn_debug_poison_lds": (c_i32, [ctypes.c_uint32, c_vp]),
+    "ggcn_lab_block_fused8": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp,
+                                      c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ggcn_debug_mfma_calibrate": (c_i32, [c_i32, c_i32, c_vp, c_vp, c_vp]),
     "ggcn_debug_block_fused_stamped": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                                c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),

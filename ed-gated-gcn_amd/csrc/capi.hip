@@ -240,6 +240,15 @@ int ggcn_gate_pool_backward_agg(const float *out, int64_t ldo, const float *stor
                                   d_ga, d_gb, d_bsum, as_stream(stream), p > 0.0f ? &d : nullptr, dh_amax);
 }
 
+int ggcn_lab_block_fused8(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
+                          const void *graph_ops2, const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
+                          const float *gate1, const float *gate2, float *x_out, int64_t ld2, float *x1, float *y1, float *pool_out,
+                          float *overlap_partial, uint64_t *stamps, ggcn_stream_t stream)
+{
+    return lab_block_fused8(X, ldx, wpack1, wpack12, graph_ops, graph_ops2, bias1, bias_mid, bias2, B, T, K, F, gate1, gate2, x_out, ld2,
+                            x1, y1, pool_out, overlap_partial, as_stream(stream), reinterpret_cast<unsigned long long *>(stamps));
+}
+
 int ggcn_rowmask_transpose(const uint32_t *rowmask, int B, int T, uint32_t *rowmask_t, ggcn_stream_t stream)
 {
     return rowmask_transpose(rowmask, B, T, rowmask_t, as_stream(stream));
@@ -339,6 +348,7 @@ int ggcn_range_flag(uint32_t *flag, int clear, ggcn_stream_t stream)
     rc = rc ? rc : range_flag_fused(flag, clear, as_stream(stream));
     rc = rc ? rc : range_flag_wide(flag, clear, as_stream(stream));
     rc = rc ? rc : range_flag_wide8(flag, clear, as_stream(stream));
+    rc = rc ? rc : range_flag_block8(flag, clear, as_stream(stream));
 #ifdef GGCN_WITH_F16MX6
     rc = rc ? rc : range_flag_fused6(flag, clear, as_stream(stream));
 #endif

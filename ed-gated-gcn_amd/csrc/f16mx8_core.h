@@ -207,15 +207,23 @@ __device__ __forceinline__ BufX<AT> make_bufx(const AT *X, int64_t ldx, int64_t 
 #endif
 // XS (ggcn_linear_scaled: the backward's dX): every value is multiplied by the power of two `xscale` before it is split -- rows
 // whose magnitudes lie anywhere in the fp32 range (gradients) are brought to |x| < 256 first; the caller undoes it at the store.
-template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false, bool BUF = false, int NB = 4, bool XS = false>
+// XP (fused_block8.hip, an experiment): this thread STAGES only XP of the tile's passes -- pass0, pass0 + 1, ... in the slots 0 ..
+// XP - 1 of arow / avalid / bufx -- while its wavefront still multiplies all NB row blocks: two four-wavefront groups of one
+// 512-thread workgroup share one set of X planes (each stages half of it) and meet at the same barriers.  SLOT0: the stage's slot
+// (= 32-row block of MFMAs) behind which this thread's first staging pass sits -- the second group takes slots 2, 3, so that the two
+// wavefronts of a SIMD (one of each group) do their split / store / load work behind DIFFERENT MFMAs.
+template <typename AT, bool AVEC, bool KFULL, bool ZROWS, bool RBLK = false, bool BUF = false, int NB = 4, bool XS = false, int XP = 4, int SLOT0 = 0>
 __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], const bool (&avalid)[Geom<AT>::NP],
                                          const char *__restrict__ wpack, int K, int stages_packed, int wm,
                                          int nt0, int n_tiles_total, char *lds, f32x16 (&acc)[4][RN], int rot = 0, int nblk = 4,
-                                         float *amax_out = nullptr, const BufX<AT> *bufx = nullptr, float xscale = 1.0f)
+                                         float *amax_out = nullptr, const BufX<AT> *bufx = nullptr, float xscale = 1.0f, int pass0 = 0)
 {
     static_assert(!BUF || (AVEC && KFULL && sizeof(AT) == 4), "buffer loads: whole 16-byte pieces of fp32 rows");
     static_assert(NB >= 1 && NB <= 4 && (NB == 4 || (sizeof(AT) == 4 && !RBLK)), "NB < 4: fp32 rows (pass i = block i), no run-time count");
-    constexpr int NPL = Geom<AT>::NP < NB ? Geom<AT>::NP : NB;   // live staging passes
+    constexpr int NPL0 = Geom<AT>::NP < NB ? Geom<AT>::NP : NB;   // live staging passes
+    constexpr int NPL = NPL0 < XP ? NPL0 : XP;                     // ... of which this thread performs XP (slot i = pass pass0 + i)
+    static_assert(XP == 4 || (sizeof(AT) == 4 && NB == 4 && !RBLK), "XP < 4: fp32 rows, whole tiles");
+    static_assert(SLOT0 >= 0 && SLOT0 + XP <= 4, "the staging passes sit behind the stage's four row-block slots");
     // rot: the K loop starts at stage `rot` and wraps around (same sum, another order).  The column
     // tiles of one row block run side by side on one XCD and read the same rows of X: started one
     // stage apart they find each other's lines in L2 instead of missing on them at the same moment.
@@ -274,7 +282,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
     auto write_pass = [&](int buf, int i) {
         char *h_plane = lds + buf * (2 * BM * ROWB);
         char *q_plane = h_plane + BM * ROWB;
-        const int row = stage_row<AT>(i);
+        const int row = stage_row<AT>(XP == 4 ? i : i + pass0);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int kq = s_k + 4 * q;  // k offset inside the 32-deep stage
@@ -460,16 +468,16 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[0], acc[i][0], 0, 0, 0);
             GGCN_SB();
-            if GGCN_ON(2) { if (i < NP && i < GGCN_LAB_XPASSES) split_pass(i, k_next1); }
+            if GGCN_ON(2) { if (i - SLOT0 >= 0 && i - SLOT0 < NP && i - SLOT0 < GGCN_LAB_XPASSES && i - SLOT0 < XP) split_pass(i - SLOT0, k_next1); }
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[1], acc[i][1], 0, 0, 0);
             GGCN_SB();
-            if GGCN_ON(4) { if (i < NP && i < GGCN_LAB_XPASSES) write_pass(buf ^ 1, i); }
+            if GGCN_ON(4) { if (i - SLOT0 >= 0 && i - SLOT0 < NP && i - SLOT0 < GGCN_LAB_XPASSES && i - SLOT0 < XP) write_pass(buf ^ 1, i - SLOT0); }
             else { _Pragma("unroll") for (int q = 0; q < NQ; ++q) asm volatile("" :: "v"(sp[q].h01), "v"(sp[q].h23), "v"(sp[q].l8), "v"(sp[q].h8)); }
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[0], acc[i][0], 0, 0, 0);
             GGCN_SB();
-            if GGCN_ON(1) { if (i < NP && i < GGCN_LAB_XPASSES) load_a_pass(i, ka); }
+            if GGCN_ON(1) { if (i - SLOT0 >= 0 && i - SLOT0 < NP && i - SLOT0 < GGCN_LAB_XPASSES && i - SLOT0 < XP) load_a_pass(i - SLOT0, ka); }
             else { if (i < NP) { _Pragma("unroll") for (int c = 0; c < EPT; ++c) asm volatile("" : "+v"(ra[i][c])); } }
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[1], acc[i][1], 0, 0, 0);

@@ -297,6 +297,58 @@ __device__ __forceinline__ void fused_range_verdict(float amax, const char *wpac
     mx8::range_verdict(amax, bw, fmaxf(fmaxf(mm.x, mm.y), fmaxf(mm.z, mm.w)), window);
 }
 
+// The epilogue's operands (EpiLds<BASE>: the 4 graphs' operand blocks, 3 x 4 gate rows, bias and mid rows) brought to LDS by LDS-DMA:
+// no registers, no wait -- stage_epilogue_operands (fused_common.h) loads them into registers and stores them, which costs a
+// workgroup alone on its CU 2.6-4.6 us in front of its main loop (tools/block8_timing.py stamps).  The pieces land under the main
+// loop's first stages (its vmcnt waits and barriers cover them long before the epilogue).  Whole tiles only (4 real graphs, 256
+// real columns, 16-byte aligned gate rows): the caller falls back otherwise.  tid: 0..255 inside the group.
+template <int BASE>
+__device__ __forceinline__ void stage_epilogue_operands_dma(const FusedArgs &a, const LayerPart &lp, int g0, int n_wgi, char *lds, int tid)
+{
+    constexpr int kEpiOps = EpiLds<BASE>::kOps, kEpiGate = EpiLds<BASE>::kGate, kEpiBias = EpiLds<BASE>::kBias;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int F = a.F;
+    const bool second = lp.mid != nullptr;
+    const int total = 4 * (second ? kOps2Bytes : kOpsBytes);
+    const char *src = (second ? a.graph_ops2 : a.graph_ops) + (int64_t)g0 * (second ? kOps2Bytes : kOpsBytes);
+    for (int piece = wave; piece * 1024 < total; piece += 4)
+        if (piece * 1024 + lane * 16 < total)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(lds + kEpiOps + piece * 1024), 16, 0, 0);
+    const float *gp[3] = {lp.store_gate, lp.pool_gate_a, lp.pool_gate_b};
+    float *gl = reinterpret_cast<float *>(lds + kEpiGate);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (gp[k]) {   // (workgroup-uniform) wavefront w brings graph w's row of this gate: 1 KiB = 256 columns
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp[k] + (int64_t)(g0 + wave) * F + n_wgi * BN + lane * 4),
+                                             (__attribute__((address_space(3))) void *)(lds + kEpiGate + ((k * 4 + wave) * BN) * 4), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gl[(k * 4 + i) * BN + tid] = 1.0f;
+        }
+    }
+    float *bl = reinterpret_cast<float *>(lds + kEpiBias);
+    if (lp.bias) {
+        if (wave == 0) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(lp.bias + n_wgi * BN + lane * 4),
+                                                        (__attribute__((address_space(3))) void *)(lds + kEpiBias), 16, 0, 0);
+    } else bl[tid] = 0.0f;
+    if (lp.mid) {
+        if (wave == 1) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(lp.mid + n_wgi * BN + lane * 4),
+                                                        (__attribute__((address_space(3))) void *)(lds + kEpiBias + BN * 4), 16, 0, 0);
+    } else bl[BN + tid] = 0.0f;
+}
+// the range verdict with max |mid| taken from the staged row by every wavefront itself (no cross-wavefront hand-over)
+template <int BASE>
+__device__ __forceinline__ void dma_range_verdict(float amax, const char *wpack, int64_t pack_bytes, const char *lds, int lane)
+{
+    const float4 m4 = *reinterpret_cast<const float4 *>(lds + EpiLds<BASE>::kBias + BN * 4 + lane * 16);
+    float mm = fmaxf(fmaxf(fabsf(m4.x), fabsf(m4.y)), fmaxf(fabsf(m4.z), fabsf(m4.w)));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mm = fmaxf(mm, __shfl_xor(mm, d));
+    const float bw = *reinterpret_cast<const float *>(wpack + pack_bytes);
+    mx8::range_verdict(amax, bw, mm, true);
+}
+
 // plain v_max / v_min (fmaxf first quiets a possible signalling NaN of an operand the compiler cannot prove canonical -- after a
 // lane exchange, say: one extra instruction per operand)
 __device__ __forceinline__ float vmax_raw(float x, float y) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; }

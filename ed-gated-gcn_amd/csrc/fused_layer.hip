@@ -183,6 +183,19 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
         arow[i] = a.X + node * a.ldx;
     }
 
+#if !GGCN_LAB_NO_DMA_STAGE
+    // Round 5: whole tiles with aligned rows bring the epilogue's operands to LDS by LDS-DMA (stage_epilogue_operands_dma,
+    // fused_common.h: no registers, no wait in front of the main loop) -- block 618.3 -> 608.6 us, a 512-graph shard 83.0 -> 82.1 us
+    // in the same process, bit-identical (found on the eight-wavefront experiment, fused_block8.hip, where the register form of the
+    // staging stands alone on its CU: 4.7 -> 1.5 us per workgroup)
+    const bool dma_stage = SCH == 1 && (a.n_wg * BN == F) && (gt0 + 4 <= B) && a.drop.thr == 0 && (F % 4 == 0) &&
+                           ((reinterpret_cast<uintptr_t>(lp.store_gate) | reinterpret_cast<uintptr_t>(lp.pool_gate_a) | reinterpret_cast<uintptr_t>(lp.pool_gate_b) |
+                             reinterpret_cast<uintptr_t>(lp.bias) | reinterpret_cast<uintptr_t>(lp.mid)) & 15u) == 0;
+    if (dma_stage) stage_epilogue_operands_dma<kLdsBytes>(a, lp, g0, n_wgi, lds, tid);
+    else
+#else
+    constexpr bool dma_stage = false;
+#endif
     stage_epilogue_operands<kLdsBytes>(a, lp, g0, n_wgi, lds, tid);   // g0 = gt0: one wavefront row
     f32x16 acc[4][RN];
     GGCN_TRACE(4);
@@ -210,7 +223,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void layer_fused_kernel(co
         }
         mx8::mainloop<float, AVEC, KFULL, !FULLT, false, BUF>(arow, avalid, wpack, K, a.k_steps / 2, wm, nt0, n_tiles_total, lds, acc, 0, 4,
                                                              &amax, &bx);
-        fused_range_verdict<kLdsBytes>(amax, wpack, (int64_t)n_tiles_total * (a.k_steps / 2) * mx8::STAGE_PACK_BYTES, lds, true);
+        if (dma_stage) dma_range_verdict<kLdsBytes>(amax, wpack, (int64_t)n_tiles_total * (a.k_steps / 2) * mx8::STAGE_PACK_BYTES, lds, tid & 63);
+        else fused_range_verdict<kLdsBytes>(amax, wpack, (int64_t)n_tiles_total * (a.k_steps / 2) * mx8::STAGE_PACK_BYTES, lds, true);
     }
     GGCN_TRACE(5);
     if constexpr (STAMP) {

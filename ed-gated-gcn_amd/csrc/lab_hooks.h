@@ -31,6 +31,9 @@
 #ifndef GGCN_LAB_OFF
 #define GGCN_LAB_OFF 0
 #endif
+#ifndef GGCN_LAB_NO_DMA_STAGE
+#define GGCN_LAB_NO_DMA_STAGE 0   // 1: the 32-node kernel stages its epilogue operands through registers as before round 5 (A/B switch)
+#endif
 // timing-only: staging passes (X loads, split, plane writes) a thread performs per stage (4 = all; 2 prices a workgroup of
 // eight wavefronts that shares one set of X planes between two column halves; wrong results below 4)
 #ifndef GGCN_LAB_XPASSES

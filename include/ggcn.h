@@ -471,6 +471,14 @@ int ggcn_debug_poison_lds(uint32_t pattern, ggcn_stream_t stream);
  * uint64[2 * workgroups], workgroups = ceil(B/16) * ceil(F/256) * 8): same results, a few percent slower; no product launch
  * executes a stamp. */
 int ggcn_debug_mfma_calibrate(int n_wg, int stages, uint64_t *stamps, float *sink, ggcn_stream_t stream);
+/* EXPERIMENT, called by nothing in the product (tools/block8_timing.py, one parity test): ggcn_block_fused's tiles in workgroups of
+ * EIGHT wavefronts that share a row block's X planes between the W1 and the W12 column tiles of a 256-column slice (f16mx8, T <= 32,
+ * K % 32 == 0, 16-byte rows, no gcn1).  Bit-identical results; measured slower. */
+int ggcn_lab_block_fused8(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
+                          const void *graph_ops2, const float *bias1, const float *bias_mid, const float *bias2,
+                          int B, int T, int K, int F, const float *gate1, const float *gate2, float *x_out, int64_t ld2,
+                          float *x1, float *y1, float *pool_out, float *overlap_partial, uint64_t *stamps, ggcn_stream_t stream);
+/* (stamps: NULL, or uint64[workgroups * 2 groups * 4]: s_memrealtime at workgroup start / main loop start / main loop end / end) */
 int ggcn_debug_block_fused_stamped(const float *X, int64_t ldx, const void *wpack1, const void *wpack12,
                                    const void *graph_ops, const void *graph_ops2, const float *bias1, const float *bias_mid,
                                    const float *bias2, int B, int T, int K, int F, const float *gate1, const float *gate2,
