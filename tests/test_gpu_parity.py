@@ -1734,6 +1734,53 @@ def test_precomputed_edge_lists_of_the_eight_wavefront_layer(pkg, dev, B, T, F):
     assert lib.ggcn_graph_edge_lists(P(csr.rowmask), B, 100, P(lists), st) != 0      # 33..128 nodes: another kernel, no lists
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,H", [(16, 32, 256), (37, 23, 256), (5, 32, 768), (3, 7, 64)])
+def test_eight_wavefront_shared_x_experiment_is_bit_identical_to_the_block(pkg, dev, B, T, H):
+    """ggcn_lab_block_fused8 (one workgroup of eight wavefronts shares a row block's X planes between its W1
+    and W12 column tiles; an experiment nothing in the product calls): the same tiles, arithmetic and order as ggcn_block_fused,
+    so x, x1, y1, out and the regulariser's partials are the same bits -- whole and ragged batches, both XCD mappings, with and
+    without the [N,F] output."""
+    from ed_gated_gcn_amd import _capi, synth
+    from ed_gated_gcn_amd.gated_block import _block_operands
+    lib = pkg.load_library()
+    rng = np.random.default_rng(B + T + H)
+    adj = synth.dependency_batch(B, T, min(4.0, T), seed=6, lengths=rng.integers(1, T + 1, size=B))
+    rp, ci, _ = synth.csr_from_dense_host(adj)
+    csr = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev)
+    x = torch.from_numpy(rng.standard_normal((B * T, H)).astype(np.float32)).to(dev)
+    g1, g2 = torch.rand(B, H, device=dev), torch.rand(B, H, device=dev)
+    (w1, b1), (w2, b2) = synth.layer_params(H, H, seed=1), synth.layer_params(H, H, seed=2)
+    l1, l2 = _layer(pkg, dev, w1, b1, "f16mx8"), _layer(pkg, dev, w2, b2, "f16mx8")
+    st, P = _capi.stream_of(dev), _capi.ptr
+    pack1, pack12, mid = _block_operands(l1, l2, lib, st, precision="f16mx8")
+    bb1, bb2 = l1.bias.detach(), l2.bias.detach()
+    npart = (H + 63) // 64
+
+    def bufs():
+        e = lambda *s: torch.full(s, float("nan"), device=dev)   # noqa: E731
+        return dict(xo=e(B * T, H), x1=e(B, H), y1=e(B, H), out=e(B, H), part=e(B, npart))
+    ref = bufs()
+    _capi.check(lib.ggcn_block_fused(P(x), H, P(pack1), P(pack12), P(csr.graph_ops), P(csr.graph_ops2(1)), P(bb1), P(mid), P(bb2), B, T, H, H,
+                                     P(g1), P(g2), None, H, P(ref["xo"]), H, P(ref["x1"]), P(ref["y1"]), P(ref["out"]), P(ref["part"]),
+                                     _capi.PREC["f16mx8"], st), "ggcn_block_fused")
+    for rowmajor in (False, True):
+        if rowmajor:
+            os.environ["GGCN_LAB_BLOCK8_ROWMAJOR"] = "1"
+        try:
+            for with_x in (True, False):
+                r = bufs()
+                _capi.check(lib.ggcn_lab_block_fused8(P(x), H, P(pack1), P(pack12), P(csr.graph_ops), P(csr.graph_ops2(1)), P(bb1), P(mid), P(bb2),
+                                                      B, T, H, H, P(g1), P(g2), P(r["xo"]) if with_x else None, H, P(r["x1"]), P(r["y1"]),
+                                                      P(r["out"]), P(r["part"]), None, st), "ggcn_lab_block_fused8")
+                torch.cuda.synchronize()
+                for k in ("x1", "y1", "out", "part") + (("xo",) if with_x else ()):
+                    a, b = ref[k], r[k]
+                    assert bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all()), (k, rowmajor, with_x)
+        finally:
+            os.environ.pop("GGCN_LAB_BLOCK8_ROWMAJOR", None)
+
+
 # ---------------------------------------------------------------- N > 1 product path on one device (SURVEY 8e)
 def _shard_worker(rank, world, port, ret):
     import traceback
