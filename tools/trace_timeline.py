@@ -27,7 +27,7 @@ x = torch.randn(B * T, H, generator=gen).to(dev)
 w = (torch.randn(H, H, generator=gen) * 0.05).to(dev)
 b = torch.randn(H, generator=gen).to(dev)
 g1 = torch.sigmoid(torch.randn(B, H, generator=gen)).to(dev); g2 = torch.sigmoid(torch.randn(B, H, generator=gen)).to(dev)
-out = torch.empty(B * T, H, device=dev); pa = torch.empty(B, H, device=dev); pb = torch.empty(B, H, device=dev)
+out = torch.empty(B * T, H, device=dev); pa = torch.empty(B, H, device=dev); pb = torch.empty(B, H, device=dev); pc = torch.empty(B, H, device=dev)
 p = _capi.ptr
 pack = torch.empty(lib.ggcn_weight_pack_bytes(H, H, prec), dtype=torch.uint8, device=dev)
 assert lib.ggcn_weight_pack(p(w), H, H, H, prec, 0, p(pack), None) == 0
@@ -36,8 +36,8 @@ assert lib.ggcn_weight_pack(p(w.t().contiguous()), H, H, H, prec, 0, p(pack12), 
 part = torch.empty(B, 12, device=dev)
 def run():
     if BLOCK:
-        rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack12), p(csr.graph_ops), p(b), p(b), p(b), B, T, H, H, p(g1), p(g2),
-                                  None, H, p(out), H, p(pa), p(pb), p(pa), p(part), prec, None)
+        rc = lib.ggcn_block_fused(p(x), H, p(pack), p(pack12), p(csr.graph_ops), p(csr.graph_ops2(0 if prec == 0 else 1)), p(b), p(b), p(b), B, T, H, H,
+                                  p(g1), p(g2), None, H, p(out), H, p(pa), p(pb), p(pc), p(part), prec, None)
         assert rc == 0
         return
     rc = lib.ggcn_layer_fused(p(x), H, p(pack), p(csr.rowmask), p(csr.graph_ops), p(b), B, T, H, H, None, p(g1), p(g2), None if NOOUT else p(out), H,
