@@ -59,6 +59,11 @@ constexpr int kCodeZero = LR << 2;
 #ifndef GGCN_LAB_LONG
 #define GGCN_LAB_LONG 0
 #endif
+// timing-only switches of the main loop's fill (lab builds; wrong results): 1 all ten pieces of the next stage at the top of the
+// stage, 2 no W pieces, 4 no X pieces, 8 only the first four X pieces, 16 no MFMAs / fragment reads, 32 X in half-line pieces
+#ifndef GGCN_LAB_LONG_MAIN
+#define GGCN_LAB_LONG_MAIN 0
+#endif
 #ifndef GGCN_LAB_LONG_AUX
 #define GGCN_LAB_LONG_AUX 2     // cache policy of the row stores (buffer intrinsic aux: 1 sc0, 2 nt, 16 sc1)
 #endif
@@ -174,7 +179,14 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
         const int bdst = 2 * kDmaA + ((wave >> 1) * 4 + 2 * (wave & 1)) * 1024;
         auto issue_piece = [&](int t, int st, int buf) {   // t = 0..7: X piece t; 8, 9: the two k-steps of this wavefront's W record
             st = st < stages ? st : stages - 1;
-            if (t < 8) {
+            if (((GGCN_LAB_LONG_MAIN) & 2) && t >= 8) return;
+            if (((GGCN_LAB_LONG_MAIN) & 4) && t < 8) return;
+            if (((GGCN_LAB_LONG_MAIN) & 8) && t >= 4 && t < 8) return;
+            if (((GGCN_LAB_LONG_MAIN) & 32) && t < 8) {   // half-line pieces: 16 rows x 64 B, the k-low halves first (t < 4), the k-high halves later
+                const int row = 128 * (t & 3) + 16 * wave + (lane >> 2);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.X + (node0 + row) * a.ldx + 8 * ((lane & 3) + 4 * (t >> 2)) + st * LBK),
+                                                 (__attribute__((address_space(3))) void *)(lds + buf * kDmaA + (64 * t + 8 * wave) * 128), 16, 0, GGCN_LAB_LONG_XAUX);
+            } else if (t < 8) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc[t] + st * LBK),
                                                  (__attribute__((address_space(3))) void *)(lds + buf * kDmaA + (64 * t + 8 * wave) * 128), 16, 0, GGCN_LAB_LONG_XAUX);
             } else {
@@ -187,9 +199,11 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
         const int sw = ((lane & 31) >> 1) & 7;
         const int aoff = (128 * rg + (lane & 31)) * 128;
         auto read_a = [&](int buf, int s, int i, f16x8 &af) {
+            if ((GGCN_LAB_LONG_MAIN) & 128) { asm volatile("" : "+v"(af)); return; }
             af = *reinterpret_cast<const f16x8 *>(lds + buf * kDmaA + aoff + i * 4096 + (((2 * s + khalf) ^ sw) << 4));
         };
         auto read_b = [&](int buf, int s, f16x8 (&bf)[RN]) {
+            if ((GGCN_LAB_LONG_MAIN) & 256) { asm volatile("" : "+v"(bf[0]), "+v"(bf[1])); return; }
 #pragma unroll
             for (int j = 0; j < RN; ++j)
                 bf[j] = *reinterpret_cast<const f16x8 *>(lds + 2 * kDmaA + buf * kDmaB + ((2 * cg + j) * 4 + s) * 1024 + 16 * lane);
@@ -204,6 +218,16 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
             constexpr int buf = decltype(bufc)::value;
             constexpr int AH = 2;     // X fragment reads run two steps (of 2 MFMAs) ahead of their use, W fragments of a k-step three
             f16x8 af[AH + 1], bf[2][RN];
+            if ((GGCN_LAB_LONG_MAIN) & 1) {
+#pragma unroll
+                for (int t = 0; t < 10; ++t) issue_piece(t, st + 1, buf ^ 1);
+            }
+            if ((GGCN_LAB_LONG_MAIN) & 16) {
+#pragma unroll
+                for (int t = 0; t < 10; ++t) issue_piece(t, st + 1, buf ^ 1);
+                __syncthreads();
+                return;
+            }
             read_b(buf, 0, bf[0]);
 #pragma unroll
             for (int t = 0; t < AH; ++t) read_a(buf, t >> 2, t & 3, af[t]);
@@ -218,12 +242,13 @@ __global__ __launch_bounds__(LTHR, 2) void layer_fused_long_kernel(const LongArg
                     GGCN_SB();
                     acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t % (AH + 1)], bf[s4 & 1][0], acc[i][0], 0, 0, 0);
                     GGCN_SB();
-                    if (t < 10) issue_piece(t, st + 1, buf ^ 1);
+                    if (t < 10 && !((GGCN_LAB_LONG_MAIN) & 1)) issue_piece(t, st + 1, buf ^ 1);
                     GGCN_SB();
                     acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t % (AH + 1)], bf[s4 & 1][1], acc[i][1], 0, 0, 0);
                     GGCN_SB();
                 }
-            __syncthreads();
+            if ((GGCN_LAB_LONG_MAIN) & 64) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");   // timing of a ring one stage deeper: waits for the pieces of the stage BEFORE
+            else __syncthreads();
         };
         int st = 0;
         for (; st + 1 < stages; st += 2) {

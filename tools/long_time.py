@@ -40,15 +40,43 @@ for name, (lib, _) in variants.items():
     assert lib.ggcn_weight_pack(p(w), H, H, H, 3, 0, p(pack), None) == 0
     packs[name] = pack
 
+# LONG_LDX="1032,1088": the product library again with X rows that far apart (elements) -- does the 2 KiB row pitch cost L2 channels?
+xpad = {}
+for ld in [int(v) for v in os.environ.get("LONG_LDX", "").split(",") if v]:
+    buf = torch.zeros(B * T, ld, device=dev, dtype=torch.float16)
+    buf[:, :H] = x
+    n = "main, ldx %d" % ld
+    variants[n] = (main, None); packs[n] = packs["main, MFMA sums"]; xpad[n] = (buf, ld)
+
 def run(name):
     lib, env = variants[name]
+    xx, ldx = xpad.get(name, (x, H))
     if env: os.environ["GGCN_LONG_LANE_SUMS"] = env
     else: os.environ.pop("GGCN_LONG_LANE_SUMS", None)
-    assert lib.ggcn_layer_fused_h(p(x), H, p(packs[name]), p(csr.rowptr), p(csr.colidx), None, p(b), B, T, H, H, p(g2), p(g1), p(g2),
+    assert lib.ggcn_layer_fused_h(p(xx), ldx, p(packs[name]), p(csr.rowptr), p(csr.colidx), None, p(b), B, T, H, H, p(g2), p(g1), p(g2),
                                   p(out), H, p(pa), p(pb), None) == 0
 
 for _ in range(100): run("main, MFMA sums")
 torch.cuda.synchronize()
+if os.environ.get("LAB_ENERGY"):   # each variant alone for ~1.5 s with the board power from sysfs beside it -> energy per launch
+    import bench, time
+    for n in variants:
+        for _ in range(300): run(n)
+        torch.cuda.synchronize()
+        with bench.PowerSampler() as ps:
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t_end, cnt = time.perf_counter() + 1.5, 0
+            a.record()
+            while time.perf_counter() < t_end:
+                for _ in range(100): run(n)
+                cnt += 100
+                torch.cuda.synchronize()
+            e.record(); torch.cuda.synchronize()
+        us, pw = a.elapsed_time(e) / cnt * 1e3, ps.summary()
+        print("%-24s %8.1f us per launch   %7.1f W (max %7.1f, sclk %s MHz)   %.4f J per launch" %
+              (n, us, pw.get("power_w") or float("nan"), pw.get("power_w_max") or float("nan"), pw.get("sclk_dpm_mhz"),
+               us * 1e-6 * (pw.get("power_w") or float("nan"))), flush=True)
+    sys.exit(0)
 times = {n: [] for n in variants}
 for rnd in range(12):
     for n in variants:
