@@ -61,7 +61,7 @@ class BatchedCSR:
     kernel: all the fused layer needs); the CSR arrays are materialised on first access."""
 
     __slots__ = ("_rowptr", "_colidx", "_vals", "rowmask", "B", "T", "nnz", "is_binary",
-                 "_dense", "_dense_version", "_t", "_inv", "_graph_ops", "_graph_ops2", "_graph_ops_t", "_edge_lists", "__weakref__")
+                 "_dense", "_dense_version", "_t", "_inv", "_graph_ops", "_graph_ops2", "_graph_ops_t", "_edge_lists", "_graph_ops_w", "__weakref__")
 
     def __init__(self, rowptr, colidx, vals, B, T, nnz=None, rowmask=None):
         self._rowptr, self._colidx, self._vals, self.rowmask = rowptr, colidx, vals, rowmask
@@ -75,6 +75,7 @@ class BatchedCSR:
         self._graph_ops2 = None  # cached ggcn_graph_operands2 blocks per plane type (the one-launch block)
         self._graph_ops_t = None  # cached ggcn_graph_operands blocks of the TRANSPOSED row masks (the MFMA backward)
         self._edge_lists = None   # cached ggcn_graph_edge_lists blocks (graphs of 129..256 nodes: the eight-wavefront layer)
+        self._graph_ops_w = None  # cached ggcn_graph_operands_weighted blocks per plane type (real-valued adjacency, <= 32 nodes)
 
     @property
     def graph_ops(self):
@@ -137,6 +138,28 @@ class BatchedCSR:
                 _capi.check(lib.ggcn_graph_operands2(_capi.ptr(self.rowmask), self.B, self.T, plane, _capi.ptr(ops),
                                                      _capi.stream_of(dev)), "ggcn_graph_operands2")
             store[plane] = ops
+        return store[plane]
+
+    def graph_ops_weighted(self, plane):
+        """uint8 [B * GGCN_GRAPH_OPS2_BYTES] or None: a REAL-valued adjacency of graphs of <= 32 nodes as the one-launch
+        layer's operand (``ggcn_graph_operands_weighted``: D.A_w as hi / lo parts in the plane type, 0 = bf16 pairs, 1 = fp16
+        pairs), built from the CSR arrays on first use.  None when an entry does not fit the plane type (one read-back of
+        the builder's flag per adjacency and plane type): that adjacency keeps linear + aggregate."""
+        store = self._graph_ops_w
+        if store is None:
+            store = self._graph_ops_w = {}
+        if plane not in store:
+            if self.T > 32 or not self.rowptr.is_cuda:
+                return None
+            lib = _capi.load_library()
+            dev = self.rowptr.device
+            ops = torch.empty(lib.ggcn_graph_operands2_bytes(self.B), dtype=torch.uint8, device=dev)
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _capi.check(lib.ggcn_graph_operands_weighted(_capi.ptr(self.rowptr), _capi.ptr(self.colidx), _capi.ptr(self.vals),
+                                                             self.B, self.T, plane, _capi.ptr(ops), _capi.ptr(flag),
+                                                             _capi.stream_of(dev)), "ggcn_graph_operands_weighted")
+            store[plane] = None if int(flag.item()) else ops
         return store[plane]
 
     @property

@@ -110,6 +110,22 @@ int ggcn_layer_fused_prebias(const float *X, int64_t ldx, const void *wpack, con
                        ldo, pool_a, pool_b, nullptr, nullptr, nullptr, precision, as_stream(stream), nullptr, bias_pre);
 }
 
+int ggcn_graph_operands_weighted(const int32_t *rowptr, const int32_t *colidx, const float *vals, int B, int T, int plane,
+                                 void *graph_opsw, int32_t *flag, ggcn_stream_t stream)
+{
+    return graph_operands_weighted(rowptr, colidx, vals, B, T, plane, graph_opsw, flag, as_stream(stream));
+}
+
+int ggcn_layer_fused_weighted(const float *X, int64_t ldx, const void *wpack, const void *graph_opsw, const float *bias,
+                              const float *zero_mid, int B, int T, int K, int F, const float *store_gate,
+                              const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo, float *pool_a,
+                              float *pool_b, float *overlap_partial, const float *overlap_in, float *overlap_out, int precision,
+                              ggcn_stream_t stream)
+{
+    return layer_fused_weighted(X, ldx, wpack, graph_opsw, bias, zero_mid, B, T, K, F, store_gate, pool_gate_a, pool_gate_b, out, ldo,
+                                pool_a, pool_b, overlap_partial, overlap_in, overlap_out, precision, as_stream(stream));
+}
+
 int ggcn_block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
                      const void *graph_ops2, const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
                      const float *gate1, const float *gate2, float *gcn1, int64_t ld1, float *x_out, int64_t ld2,

@@ -74,6 +74,12 @@ int csr_rowmask(const int32_t *rowptr, const int32_t *colidx, int B, int T, uint
 int graph_operands(const uint32_t *rowmask, int B, int T, void *ops, hipStream_t st);
 int graph_edge_lists(const uint32_t *rowmask, int B, int T, void *lists, hipStream_t st);   // fused_wide8.hip
 int graph_operands2(const uint32_t *rowmask, int B, int T, int plane, void *ops2, hipStream_t st);
+int graph_operands_weighted(const int32_t *rowptr, const int32_t *colidx, const float *vals, int B, int T, int plane, void *ops,
+                            int *flag, hipStream_t st);
+int layer_fused_weighted(const float *X, int64_t ldx, const void *wpack, const void *graph_opsw, const float *bias, const float *zero_mid,
+                         int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
+                         float *out, int64_t ldo, float *pool_a, float *pool_b, float *overlap_partial, const float *overlap_in,
+                         float *overlap_out, int precision, hipStream_t st);
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops, const float *bias,
                 int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a,
                 const float *pool_gate_b, float *out, int64_t ldo, float *pool_a, float *pool_b,

@@ -125,6 +125,64 @@ __global__ __launch_bounds__(256) void graph_operands2_kernel(const uint32_t *__
     if (lane < 32) reinterpret_cast<float *>(blk + 4096)[lane] = (float)__popc(mrow) / (float)(__popc(mrow) + 1);
 }
 
+// ggcn_graph_operands_weighted: a REAL-valued adjacency (gcn.py:33 takes any `adj`; the reference's own graphs are 0/1) in the
+// format of the (D.A)^2 blocks above, so that the one-launch layer's MID epilogue applies it: M = D.A_w with
+// D = diag(1 / (rowsum(A_w) + 1)) (gcn.py:35), scaled by 2^10, as hi / lo fragments of the plane type; the rowsum field is 0 (no
+// `mid` bias rides along).  One wavefront per graph, lane (r, h) walks row r of the CSR (edges in CSR order, as ggcn_aggregate
+// sums them) and keeps the 16 columns its fragments hold.  flag (optional): bit 0 is set when an entry does not fit the plane
+// type (|M| * 2^10 >= 60000 in fp16 planes, or not finite) -- the caller then keeps linear + aggregate.
+template <int PLANE>
+__global__ __launch_bounds__(256) void graph_operands_w_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                               const float *__restrict__ vals, int B, int T, char *__restrict__ ops,
+                                                               int *__restrict__ flag)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= B) return;   // wavefront-uniform
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t node0 = (int64_t)g * T;
+    float a[16], wsum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a[e] = 0.0f;
+    if (r < T) {
+        const int e1 = rowptr[node0 + r + 1];
+        for (int e = rowptr[node0 + r]; e < e1; ++e) {
+            const int c = colidx[e] - (int)node0;
+            const float w = vals ? vals[e] : 1.0f;
+            wsum += w;
+            // column c sits in k-step c >> 4 as element 4 ((c >> 3) & 1) + (c & 3) of the lane half (c >> 2) & 1
+            const int idx = ((unsigned)c < 32u && ((c >> 2) & 1) == h) ? (c >> 4) * 8 + ((c >> 3) & 1) * 4 + (c & 3) : -1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] += idx == q ? w : 0.0f;
+        }
+    }
+    const float inv = 1.0f / (wsum + 1.0f);   // gcn.py:35
+    char *blk = ops + (int64_t)g * kOps2Bytes;
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        union { uint4 q; unsigned short u[8]; } hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = a[8 * s + e] * inv * kM2Scale;
+            bad = bad || !(fabsf(v) < (PLANE == 1 ? 60000.0f : 3.0e38f));
+            if constexpr (PLANE == 1) {
+                const _Float16 vh = (_Float16)v, vl = (_Float16)(v - (float)vh);
+                hi.u[e] = __builtin_bit_cast(unsigned short, vh);
+                lo.u[e] = __builtin_bit_cast(unsigned short, vl);
+            } else {
+                const __bf16 vh = (__bf16)v, vl = (__bf16)(v - (float)vh);
+                hi.u[e] = __builtin_bit_cast(unsigned short, vh);
+                lo.u[e] = __builtin_bit_cast(unsigned short, vl);
+            }
+        }
+        *reinterpret_cast<uint4 *>(blk + s * 1024 + lane * 16) = hi.q;
+        *reinterpret_cast<uint4 *>(blk + 2048 + s * 1024 + lane * 16) = lo.q;
+    }
+    if (lane < 32) reinterpret_cast<float *>(blk + 4096)[lane] = 0.0f;
+    if (bad && flag) atomicOr(flag, 1);
+}
+
 // SCH: 0 = bf16x3 main loop, 1 = f16mx8 (f16mx8_core.h)
 // FULLT: T == 32 and B % 4 == 0 (every row of every tile is a real node): drops every guard.
 // VST: the [N,F] output leaves through LDS as 16-byte row stores (needs F, ldo multiples of 4 and a 16-byte aligned out)
@@ -471,6 +529,45 @@ int graph_operands2(const uint32_t *rowmask, int B, int T, int plane, void *ops2
     if (plane == 1) hipLaunchKernelGGL(graph_operands2_kernel<1>, grid, dim3(256), 0, st, rowmask, B, T, static_cast<char *>(ops2));
     else hipLaunchKernelGGL(graph_operands2_kernel<0>, grid, dim3(256), 0, st, rowmask, B, T, static_cast<char *>(ops2));
     return check_launch("ggcn_graph_operands2");
+}
+
+int graph_operands_weighted(const int32_t *rowptr, const int32_t *colidx, const float *vals, int B, int T, int plane, void *ops,
+                            int *flag, hipStream_t st)
+{
+    const char *who = "ggcn_graph_operands_weighted";
+    if (!rowptr || !colidx || !ops) return fail(GGCN_EINVAL, "%s: null pointer", who);
+    if (B <= 0 || T <= 0) return fail(GGCN_EINVAL, "%s: B=%d T=%d must be positive", who, B, T);
+    if (T > 32) return fail(GGCN_EUNSUPPORTED, "%s: T=%d > 32 (weighted graphs of more nodes: ggcn_linear + ggcn_aggregate)", who, T);
+    if (plane != 0 && plane != 1) return fail(GGCN_EINVAL, "%s: plane %d (0 = bf16 pairs, 1 = fp16 pairs)", who, plane);
+    if (!aligned16(ops)) return fail(GGCN_EINVAL, "%s: the blocks must be 16-byte aligned", who);
+    if ((int64_t)B * T >= (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: B*T does not fit int32 node ids", who);
+    const dim3 grid((unsigned)((B + 3) / 4));
+    if (plane == 1) hipLaunchKernelGGL(graph_operands_w_kernel<1>, grid, dim3(256), 0, st, rowptr, colidx, vals, B, T, static_cast<char *>(ops), flag);
+    else hipLaunchKernelGGL(graph_operands_w_kernel<0>, grid, dim3(256), 0, st, rowptr, colidx, vals, B, T, static_cast<char *>(ops), flag);
+    return check_launch(who);
+}
+
+// gcn.py:30-45 with a real-valued adjacency for graphs of <= 32 nodes in ONE launch: the W12 column tiles' form of the block
+// (MID epilogue: one split of `hidden`, 6 MFMAs with the hi / lo operand) on ggcn_graph_operands_weighted blocks; zero_mid is the
+// all-zero `mid` row that form reads ([F] floats)
+int layer_fused_weighted(const float *X, int64_t ldx, const void *wpack, const void *graph_opsw, const float *bias, const float *zero_mid,
+                         int B, int T, int K, int F, const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
+                         float *out, int64_t ldo, float *pool_a, float *pool_b, float *overlap_partial, const float *overlap_in,
+                         float *overlap_out, int precision, hipStream_t st)
+{
+    const char *who = "ggcn_layer_fused_weighted";
+    if ((overlap_in == nullptr) != (overlap_out == nullptr)) return fail(GGCN_EINVAL, "%s: overlap_in and overlap_out go together", who);
+    if (!graph_opsw || !zero_mid) return fail(GGCN_EINVAL, "%s: the weighted operand blocks and the zero row are required", who);
+    if (T > 32) return fail(GGCN_EUNSUPPORTED, "%s: T=%d > 32 (use ggcn_linear + ggcn_aggregate)", who, T);
+    if (precision == GGCN_PREC_F16MX6) return fail(GGCN_EUNSUPPORTED, "%s: bf16x3 or f16mx8", who);
+    if (out && ldo > (int64_t)INT32_MAX) return fail(GGCN_EUNSUPPORTED, "%s: ldo too large", who);
+    FusedArgs a = {};
+    a.X = X; a.ldx = ldx; a.graph_ops = static_cast<const char *>(graph_opsw); a.graph_ops2 = a.graph_ops;
+    a.ov_in = overlap_in; a.ov_out = overlap_out;
+    a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = 1;
+    a.part[0] = LayerPart{static_cast<const char *>(wpack), bias, zero_mid, nullptr, store_gate, pool_gate_a, pool_gate_b,
+                          out, pool_a, pool_b, overlap_partial, (int)ldo};
+    return launch_fused(who, a, precision, st);
 }
 
 int layer_fused(const float *X, int64_t ldx, const void *wpack, const uint32_t *rowmask, const void *graph_ops,

@@ -367,6 +367,15 @@ class GraphConvolution(nn.Module):
         rounds = -(-wgs // cus)
         return rounds >= 2 and wgs >= self.WIDE_AUTO_FILL * rounds * cus
 
+    def takes_weighted_path(self, text, csr):
+        """True when ``forward_gated`` (inference) will run a REAL-valued adjacency (``gcn.py:33`` accepts any ``adj``) as ONE
+        launch (``ggcn_layer_fused_weighted``): graphs of <= 32 nodes, float32 features, a split-precision linear, every entry
+        of D.A_w inside the plane type (``BatchedCSR.graph_ops_weighted``).  Anything else: linear + aggregate."""
+        if not (self.fused and self.precision in _capi.PACKED and not csr.is_binary and csr.T <= 32 and self.fused_max_t >= 32
+                and text.dtype == torch.float32 and text.is_cuda):
+            return False
+        return csr.graph_ops_weighted(0 if self.precision == "bf16x3" else 1) is not None
+
     LONG_MAX_T = 512   # include/ggcn.h GGCN_LONG_MAX_T
 
     def takes_long_path(self, text, csr):
@@ -455,7 +464,8 @@ class GraphConvolution(nn.Module):
             raise RuntimeError("overlap_partial / overlap_reduce need the one-launch layer (takes_fused_path)")
         use_long = ((not use_fused) and self.takes_long_path(text, csr) and x2d.data_ptr() % 16 == 0
                     and x2d.stride(0) % 8 == 0)   # ggcn_layer_fused_h wants 16-byte aligned rows; other views: linear_h + aggregate_h
-        hidden = None if (use_fused or use_long) else self.linear(x2d)
+        use_weighted = (not use_fused) and dropout is None and self.takes_weighted_path(text, csr)
+        hidden = None if (use_fused or use_long or use_weighted) else self.linear(x2d)
         with torch.cuda.device(dev):
             st = _capi.stream_of(dev)
             out = torch.empty(B * T, F, dtype=text.dtype, device=dev) if want_out else None
@@ -484,6 +494,19 @@ class GraphConvolution(nn.Module):
                                                  _capi.ptr(overlap_reduce[1]) if overlap_reduce else None,
                                                  _capi.PREC[kprec], st),
                             "ggcn_layer_fused")
+                return (None if out is None else out.view(B, T, F)), pa, pb
+            if use_weighted:   # real-valued adjacency, graphs of <= 32 nodes: one launch on D.A_w operand blocks
+                kprec = "bf16x3" if self.precision == "bf16x3" else "f16mx8"
+                pack = self._packed_weight(lib, st, precision=kprec)
+                zmid = getattr(self, "_zero_mid", None)
+                if zmid is None or zmid.device != dev or zmid.numel() < F:
+                    zmid = self._zero_mid = torch.zeros(F, dtype=torch.float32, device=dev)
+                _capi.check(lib.ggcn_layer_fused_weighted(_capi.ptr(x2d), x2d.stride(0), _capi.ptr(pack),
+                                                          _capi.ptr(csr.graph_ops_weighted(0 if kprec == "bf16x3" else 1)),
+                                                          _capi.ptr(bias), _capi.ptr(zmid), B, T, self.in_features, F,
+                                                          _capi.ptr(store_gate), _capi.ptr(pool_gate_a), _capi.ptr(pool_gate_b),
+                                                          _capi.ptr(out), F, _capi.ptr(pa), _capi.ptr(pb), None, None, None,
+                                                          _capi.PREC[kprec], st), "ggcn_layer_fused_weighted")
                 return (None if out is None else out.view(B, T, F)), pa, pb
             if use_long:   # long fp16 graphs (BASELINE configs[3]): linear + aggregation in one launch, hidden stays in LDS
                 pack = self._packed_weight(lib, st)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GGCN_ABI_VERSION 12
+#define GGCN_ABI_VERSION 13
 #define GGCN_MASK_MAX_T 256   /* largest graph the row-mask (one-launch) path takes */
 
 typedef void *ggcn_stream_t;
@@ -334,6 +334,24 @@ int ggcn_layer_fused_prebias(const float *X, int64_t ldx, const void *wpack, con
                              const float *bias, const float *bias_pre, int B, int T, int K, int F,
                              const float *store_gate, const float *pool_gate_a, const float *pool_gate_b,
                              float *out, int64_t ldo, float *pool_a, float *pool_b, int precision, ggcn_stream_t stream);
+
+/* The one-launch layer for a REAL-valued adjacency (models/gcn.py:33-41 take any `adj`: denom = rowsum(adj) + 1,
+ * adj.hidden / denom; the reference's own graphs are 0/1, graph.py:66-74), graphs of <= 32 nodes:
+ * ggcn_graph_operands_weighted turns the batched CSR with its weights (vals; NULL = all ones) into one operand block per
+ * graph, M = D.A_w * 2^10 as hi / lo parts in the launch's plane type (`plane` as in ggcn_graph_operands2, same size:
+ * ggcn_graph_operands2_bytes(B)); *flag (optional, device memory, zeroed by the caller) gets bit 0 when an entry does not
+ * fit the plane type (|w / (rowsum + 1)| >= ~58 with fp16 planes, or a non-finite value: mixed-sign weights can do that) --
+ * such an adjacency stays with ggcn_linear + ggcn_aggregate.  ggcn_layer_fused_weighted is ggcn_layer_fused on those blocks:
+ * one split of `hidden` and 6 MFMAs per tile (hi.hi, hi.lo, lo.hi; the lo.lo term is 2^-22 of the result) where the 0/1
+ * form needs 4, sums within 2^-21 of ggcn_aggregate's fp32 sums.  zero_mid: [F] zeros, 16-byte aligned (the kernel's
+ * `mid` row, unused here).  Inference only (no gate dropout); other arguments as in ggcn_layer_fused. */
+int ggcn_graph_operands_weighted(const int32_t *rowptr, const int32_t *colidx, const float *vals, int B, int T, int plane,
+                                 void *graph_opsw, int32_t *flag, ggcn_stream_t stream);
+int ggcn_layer_fused_weighted(const float *X, int64_t ldx, const void *wpack, const void *graph_opsw, const float *bias,
+                              const float *zero_mid, int B, int T, int K, int F, const float *store_gate,
+                              const float *pool_gate_a, const float *pool_gate_b, float *out, int64_t ldo, float *pool_a,
+                              float *pool_b, float *overlap_partial, const float *overlap_in, float *overlap_out, int precision,
+                              ggcn_stream_t stream);
 
 /* ---- the whole gated block in one launch (graphs of <= 32 nodes, binary adjacency, inference) ----
  * Replaces models/bert_amir5.py:626-640 -- gc1, both gates, both max-pools, gc2, its gate and pool -- with

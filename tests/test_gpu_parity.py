@@ -2611,3 +2611,83 @@ def test_f16_precision_layer_config4_sample(pkg, dev):
         np.testing.assert_allclose(pa.cpu().numpy(), want_pa.numpy(), rtol=0, atol=2e-3)
         outs[prec] = out
     assert float((outs["f16"].float() - outs["f16mx8"].float()).abs().max()) <= 2e-3
+
+
+# ---------------------------------------------------------------- real-valued adjacency in one launch (<= 32 nodes)
+@pytest.mark.parametrize("precision", ["bf16x3", "f16mx8"])
+@pytest.mark.parametrize("B,T,K,F,signed", [(8, 32, 256, 256, False), (37, 31, 768, 768, False), (5, 17, 34, 20, False),
+                                            (3, 1, 64, 64, False), (64, 32, 128, 384, True), (9, 20, 96, 100, True)])
+def test_weighted_adjacency_layer_one_launch_vs_oracle(pkg, dev, precision, B, T, K, F, signed):
+    """gcn.py:33-41 take ANY real `adj` (denom = rowsum + 1; adj.hidden / denom): graphs of <= 32 nodes with real weights run
+    as ONE launch (ggcn_layer_fused_weighted on ggcn_graph_operands_weighted blocks) and agree with the oracle -- and, far
+    inside the gate, with linear + aggregate (fp32 sums of the same terms).  Ragged lengths; gates and both pools."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(B * 1000 + T)
+    lens = rng.integers(1, T + 1, size=B)
+    adj = synth.dependency_batch(B, T, min(3.0, T), seed=B + T, lengths=lens).astype(np.float32)
+    wts = rng.uniform(0.05, 2.0, size=adj.shape).astype(np.float32)
+    if signed:
+        wts *= np.where(rng.random(adj.shape) < 0.2, -0.25, 1.0).astype(np.float32)   # some negative weights, row sums stay > 0
+    adj = adj * wts
+    x = rng.standard_normal((B, T, K)).astype(np.float32)
+    w, b = synth.layer_params(K, F, seed=3)
+    gs, ga, gb = (torch.sigmoid(torch.from_numpy(rng.standard_normal((B, F)).astype(np.float32))).to(dev) for _ in range(3))
+    m = _layer(pkg, dev, w, b, precision)
+    xd, ad = torch.from_numpy(x).to(dev), torch.from_numpy(adj).to(dev)
+    csr = pkg.BatchedCSR.from_dense(ad)
+    assert not csr.is_binary and m.takes_weighted_path(xd, csr) and not m.takes_fused_path(xd, csr)
+    with torch.no_grad():
+        out, pa, pb = m.forward_gated(xd, csr, store_gate=gs, pool_gate_a=ga, pool_gate_b=gb, want_pool_a=True, want_pool_b=True)
+        plain = m(xd, ad)
+        m.fused = False
+        out2, pa2, pb2 = m.forward_gated(xd, csr, store_gate=gs, pool_gate_a=ga, pool_gate_b=gb, want_pool_a=True, want_pool_b=True)
+    y = ref_dense.graph_convolution(torch.from_numpy(x), torch.from_numpy(adj), torch.from_numpy(w), torch.from_numpy(b))
+    scale = max(1.0, float(y.abs().max()))
+    tol = TOL[precision] * scale
+    np.testing.assert_allclose(plain.cpu().numpy(), y.numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(out.cpu().numpy(), (y * gs.cpu()[:, None, :]).numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(pa.cpu().numpy(), (y * ga.cpu()[:, None, :]).max(1).values.numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(pb.cpu().numpy(), (y * gb.cpu()[:, None, :]).max(1).values.numpy(), rtol=0, atol=tol)
+    # against linear + aggregate: the same products, the aggregation through hi / lo parts of `hidden` and of D.A_w instead
+    # of fp32 FMAs (fp16 pairs carry 22 bits, bf16 pairs 16 -- the precision of the block's W12 tiles in that mode)
+    close = (4e-6 if precision == "f16mx8" else 6e-5) * scale
+    np.testing.assert_allclose(out.cpu().numpy(), out2.cpu().numpy(), rtol=0, atol=close)
+    np.testing.assert_allclose(pa.cpu().numpy(), pa2.cpu().numpy(), rtol=0, atol=close)
+
+
+def test_weighted_adjacency_outside_the_plane_type_keeps_two_launches(pkg, dev):
+    """Mixed-sign weights can make rowsum + 1 tiny: an entry of D.A_w beyond the fp16 planes' range sets the builder's flag and
+    the layer stays with linear + aggregate (same results as ever); bf16 planes take it.  The gated block with a real-valued
+    adjacency runs through the weighted layers and agrees with the oracle."""
+    from ed_gated_gcn_amd import synth
+    B, T, H = 6, 32, 128
+    rng = np.random.default_rng(5)
+    adj = synth.dependency_batch(B, T, 3.0, seed=9).astype(np.float32)
+    adj *= rng.uniform(0.1, 1.0, size=adj.shape).astype(np.float32)
+    bad = adj.copy()
+    bad[2, 5, :] = 0.0
+    bad[2, 5, 5], bad[2, 5, 6] = 100.0, -100.99   # rowsum + 1 = 0.01: entries of +-10^4
+    x = rng.standard_normal((B, T, H)).astype(np.float32)
+    w, b = synth.layer_params(H, H, seed=1)
+    xd = torch.from_numpy(x).to(dev)
+    m16, mb = _layer(pkg, dev, w, b, "f16mx8"), _layer(pkg, dev, w, b, "bf16x3")
+    csr_bad = pkg.BatchedCSR.from_dense(torch.from_numpy(bad).to(dev))
+    assert not m16.takes_weighted_path(xd, csr_bad) and mb.takes_weighted_path(xd, csr_bad)
+    y = ref_dense.graph_convolution(torch.from_numpy(x), torch.from_numpy(bad), torch.from_numpy(w), torch.from_numpy(b))
+    with torch.no_grad():
+        for m, prec in ((m16, "f16mx8"), (mb, "bf16x3")):
+            got = m(xd, csr_bad)
+            np.testing.assert_allclose(got.cpu().numpy(), y.numpy(), rtol=0, atol=TOL[prec] * max(1.0, float(y.abs().max())))
+    # the block (bert_amir5.py:626-640) on a real-valued adjacency
+    g1 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32)))
+    g2 = torch.sigmoid(torch.from_numpy(rng.standard_normal((B, H)).astype(np.float32)))
+    w2, b2 = synth.layer_params(H, H, seed=2)
+    l1, l2 = _layer(pkg, dev, w, b, "f16mx8"), _layer(pkg, dev, w2, b2, "f16mx8")
+    ad = torch.from_numpy(adj).to(dev)
+    assert l1.takes_weighted_path(xd, pkg.BatchedCSR.from_dense(ad))
+    with torch.no_grad():
+        r = pkg.gated_gcn_block(xd, ad, g1.to(dev), g2.to(dev), l1, l2)
+    ref = _oracle_block(x, adj, g1.numpy(), g2.numpy(), w, b, w2, b2)
+    for k in ("x1", "y1", "x", "out"):
+        np.testing.assert_allclose(r[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=TOL["f16mx8"] * max(1.0, float(ref[k].abs().max())))
+    assert abs(float(r["xy"]) - float(ref["xy"])) <= 1e-4 * max(1.0, abs(float(ref["xy"])))
