@@ -2691,3 +2691,62 @@ def test_weighted_adjacency_outside_the_plane_type_keeps_two_launches(pkg, dev):
     for k in ("x1", "y1", "x", "out"):
         np.testing.assert_allclose(r[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=TOL["f16mx8"] * max(1.0, float(ref[k].abs().max())))
     assert abs(float(r["xy"]) - float(ref["xy"])) <= 1e-4 * max(1.0, abs(float(ref["xy"])))
+
+
+@pytest.mark.parametrize("plane", [0, 1], ids=["bf16-pairs", "fp16-pairs"])
+def test_weighted_adjacency_operand_matches_numpy(pkg, dev, plane):
+    """ggcn_graph_operands_weighted through the C ABI: the device blocks -- hi + lo fragments of D.A_w * 2^10 in MFMA operand order
+    -- decoded on the host against numpy's float64 w_ij / (rowsum_i + 1) (gcn.py:35,41), ragged graphs, negative weights; a NULL
+    weight array means ones; the flag reports entries outside the plane type and nothing else."""
+    from ed_gated_gcn_amd import synth, _capi
+    lib = pkg.load_library()
+    B, T = 11, 29
+    rng = np.random.default_rng(4)
+    lens = rng.integers(1, T + 1, size=B)
+    adj = synth.dependency_batch(B, T, 4.0, seed=9, lengths=lens).astype(np.float32)
+    wadj = adj * rng.uniform(0.01, 3.0, size=adj.shape).astype(np.float32) * np.where(rng.random(adj.shape) < 0.15, -0.3, 1.0).astype(np.float32)
+    rp, ci, va = synth.csr_from_dense_host(wadj)
+    csr = pkg.BatchedCSR.from_arrays(rp, ci, B, T, dev, vals=va)
+    p = _capi.ptr
+
+    def build(vals):
+        ops = torch.zeros(lib.ggcn_graph_operands2_bytes(B), dtype=torch.uint8, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert lib.ggcn_graph_operands_weighted(p(csr.rowptr), p(csr.colidx), p(vals), B, T, plane, p(ops), p(flag), None) == 0
+        torch.cuda.synchronize()
+        return ops.cpu().numpy().reshape(B, 4224), int(flag.item())
+
+    def decode(raw):
+        def d16(u16):
+            if plane == 1:
+                return u16.view(np.float16).astype(np.float64)
+            return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        got = np.zeros((B, 32, 32))
+        for s_ in range(2):
+            hi = d16(raw[:, s_ * 1024:(s_ + 1) * 1024].copy().view(np.uint16).reshape(B, 64, 8))
+            lo = d16(raw[:, 2048 + s_ * 1024:2048 + (s_ + 1) * 1024].copy().view(np.uint16).reshape(B, 64, 8))
+            for lane in range(64):
+                r, h = lane & 31, lane >> 5
+                for e in range(8):
+                    got[:, r, 16 * s_ + 8 * (e >> 2) + 4 * h + (e & 3)] = (hi[:, lane, e] + lo[:, lane, e]) / 1024.0
+        return got
+
+    raw, flag = build(csr.vals)
+    a = wadj.astype(np.float64)
+    want = a / (a.sum(-1, keepdims=True) + 1.0)
+    got = decode(raw)
+    assert flag == 0
+    assert np.abs(got[:, :T, :T] - want).max() <= (2.0 ** -15 if plane == 0 else 2.0 ** -19) * max(1.0, np.abs(want).max())
+    assert np.abs(got[:, T:, :]).max() == 0 and np.abs(got[:, :, T:]).max() == 0
+    assert np.all(raw[:, 4096:4224].copy().view(np.float32) == 0)          # no `mid` bias rides along
+    raw1, flag1 = build(None)                                               # NULL weights: ones
+    a1 = (wadj != 0).astype(np.float64)
+    assert flag1 == 0 and np.abs(decode(raw1)[:, :T, :T] - a1 / (a1.sum(-1, keepdims=True) + 1.0)).max() <= 2.0 ** -15
+    big = csr.vals.clone()
+    e0 = int(csr.rowptr[3 * T + 2].item())
+    row_sum = float(csr.vals[e0:int(csr.rowptr[3 * T + 3].item())].sum().item())
+    big[e0] += -row_sum - 1.0 + 1e-3                                        # that row's rowsum + 1 becomes 1e-3
+    _, flag2 = build(big)
+    assert flag2 == (1 if plane == 1 else 0)                                # entries of ~10^3 * 2^10: beyond fp16, inside bf16
+    with pytest.raises(Exception):
+        _capi.check(lib.ggcn_graph_operands_weighted(p(csr.rowptr), p(csr.colidx), p(csr.vals), B, 33, plane, p(torch.zeros(64, dtype=torch.uint8, device=dev)), None, None), "T > 32")
