@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void scores_head_kernel(const float *__restric
 // in reduce_partials' order (fused_common.h) -- the one-workgroup ggcn_overlap_reduce launch rides along: at a 512-graph shard
 // the two tail launches were 13 us of a 95 us step, this one is ~4.
 constexpr int kHeadRows = 8, kHeadThreads = 1024, kHeadWaves = kHeadThreads / 64;
+static_assert(kHeadWaves == 2 * kHeadRows, "two wavefronts stage a pooled row");
 __global__ __launch_bounds__(kHeadThreads) void dense_head_kernel(const float *__restrict__ pooled, int64_t ldp, const float *__restrict__ Wt,
                                                                   int64_t ldw, const float *__restrict__ bias, int B, int H, int C,
                                                                   float *__restrict__ logits, int64_t ldl, const float *__restrict__ part,
@@ -177,9 +178,18 @@ __global__ __launch_bounds__(kHeadThreads) void dense_head_kernel(const float *_
     }
     const int b0 = blockIdx.x * kHeadRows;
     float *rows = head_lds, *red = head_lds + kHeadRows * H;
-    for (int i = tid; i < kHeadRows * H; i += kHeadThreads) {   // the workgroup's pooled rows, read once and coalesced
-        const int r = i / H, k = i - r * H;
-        rows[i] = b0 + r < B ? pooled[(int64_t)(b0 + r) * ldp + k] : 0.0f;
+    {   // the workgroup's pooled rows, read once and coalesced: wavefront (r, half) brings half of row r (no division by H)
+        const int r = wave >> 1, hb = (H + 1) >> 1, kb = (wave & 1) * hb, ke = kb + hb < H ? kb + hb : H;
+        const bool live = b0 + r < B;
+        const float *src = pooled + (int64_t)(live ? b0 + r : 0) * ldp;
+        if ((hb & 3) == 0 && (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(pooled) & 15u) == 0) {
+            for (int k = kb + 4 * lane; k < ke; k += 256) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + k);
+                *reinterpret_cast<float4 *>(rows + r * H + k) = live ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        } else {
+            for (int k = kb + lane; k < ke; k += 64) rows[r * H + k] = live ? src[k] : 0.0f;
+        }
     }
     __syncthreads();
     // lane = class, wavefront w = k-slice w of 16: every Wt row of the slice is one coalesced load, all of them independent
