@@ -82,9 +82,12 @@ def parse():
                     help="N > 1: what every rank all-gathers per step -- per-shard logits [B_r, 34] = out . Wd (north_star; the "
                          "out-dependent share of bert_amir5.py:643's dense, 70 KB per rank at 8 GPUs) or the pooled out [B_r, H] itself "
                          "(1.5 MB per rank)")
-    ap.add_argument("--gather-mode", default="async", choices=["async", "graph"],
+    ap.add_argument("--gather-mode", default="async", choices=["async", "flag", "graph"],
                     help="N > 1: async (default) = all_gather_into_tensor(async_op=True) on RCCL's own stream behind every replay, so that step "
-                         "i's gather overlaps step i+1's kernels; graph = the all-gather captured INSIDE the step's hipGraph (one graph launch "
+                         "i's gather overlaps step i+1's kernels; flag = the same eager collective issued from a side stream that "
+                         "hipStreamWaitValue32 holds until the step's head launch has counted itself done in memory (ggcn_dense_head_signal): "
+                         "no event record and no wait on the replay stream (logits payload, two-layer block, backend nccl; otherwise async); "
+                         "graph = the all-gather captured INSIDE the step's hipGraph (one graph launch "
                          "per step and no cross-stream events: 95 vs 109 us per step at a 512-graph shard with a process group of one, "
                          "DESIGN.md 6; on 8 GPUs the RCCL kernel then runs serially behind the step -- unmeasured, hence opt-in; equal shards only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -635,6 +638,12 @@ def main():
     if dist_on and args.gather == "logits":
         head = (torch.randn(H, N_CLASS, generator=torch.Generator().manual_seed(7)) / H ** 0.5).to(dev)
 
+    # --gather-mode flag: the head launch counts itself done in these two words (ggcn_dense_head_signal); the collective's side
+    # stream is gated on the count instead of on an event of the replay stream
+    flag_mode = (dist_on and args.gather_mode == "flag" and head is not None and not one_layer and args.backend == "nccl")
+    signal = torch.zeros(2, dtype=torch.int32, device=dev) if flag_mode else None
+    launched = [0]   # flag hand-off: head launches counted on the host (= the value signal[1] reaches with the newest one)
+
     def forward(xx=None, cc=None, a1=None, a2=None, path=None):
         """One pass of the hot path; returns the dict of outputs (config 4: one gated layer)."""
         xx, cc = (x if xx is None else xx), (csr if cc is None else cc)
@@ -648,9 +657,11 @@ def main():
         else:
             # N > 1: the logits head rides in the launch that finishes xy (ggcn_dense_head): block + head = two launches per step
             r = pkg.gated_gcn_block(xx, cc, a1, a2, gc1, gc2, one_launch=((path or args.path) == "block"),
-                                    dense_head=None if head is None else (head, None))
+                                    dense_head=None if head is None else ((head, None, signal) if flag_mode else (head, None)))
             if head is not None:
                 r["payload"] = r["logits"]
+            if flag_mode and not torch.cuda.is_current_stream_capturing():
+                launched[0] += 1   # a head launch that counts itself in signal[1] (a capture launches nothing; a replay counts in step())
         return r
 
     # the path's only collective: all-gather of the per-shard logits [B_r, 34] (or pooled outputs [B_r, H]), launched
@@ -695,13 +706,18 @@ def main():
             if in_graph and graphs is not None:
                 last_gathered[0] = gbufs[(counter[0] - 1) & 1]   # (filled by the replay; read after a synchronisation only)
             elif dist_on:
-                pending.append(gather.start(r["payload"] if head is not None else r["out"]))
+                if graphs is not None:
+                    launched[0] += 1   # (the replay's head launch)
+                pending.append(gather.start(r["payload"] if head is not None else r["out"],
+                                            gate=(signal, launched[0]) if flag_mode else None))
         return r
 
     def sync_all():
         while pending:
             last_gathered[0] = gather.finish(pending.pop(0))
         torch.cuda.synchronize(dev)
+        if flag_mode:   # (everything has finished: the host's count is re-read from the device, whoever launched heads meanwhile)
+            launched[0] = int(signal[1].item())
         if dist_on:
             dist.barrier()
             torch.cuda.synchronize(dev)
@@ -819,8 +835,10 @@ def main():
                 "gather_bytes_total_per_step": int(max(counts)) * width * 4 * world,
                 "payload": "logits [B_r,%d]" % N_CLASS if head is not None else "pooled out [B_r,%d]" % H,
                 "collective": ("all_gather_into_tensor captured inside the step's hipGraph, one per step" if in_graph and graphs is not None else
+                               "all_gather_into_tensor, eager, one per step, issued from a side stream held by hipStreamWaitValue32 until the "
+                               "step's head launch has counted itself done (ggcn_dense_head_signal): no event on the replay stream" if flag_mode else
                                "all_gather_into_tensor, async, one per step; shards padded to the largest B_r"),
-                "gather_mode": "graph" if in_graph and graphs is not None else "async"}
+                "gather_mode": "graph" if in_graph and graphs is not None else "flag" if flag_mode else "async"}
         if args.check_gather and args.scaling == "strong":
             got = last_gathered[0]
             if rank == 0:   # the whole batch on rank 0's GPU, one shard-sized GEMM per rank (same kernels as the ranks ran)

@@ -397,6 +397,14 @@ int ggcn_dense_head(const float *pooled, int64_t ldp, const float *Wt, int64_t l
     return dense_head(pooled, ldp, Wt, ldw, bias, B, H, C, logits, ldl, overlap_partials, F_block, xy, as_stream(stream));
 }
 
+int ggcn_dense_head_signal(const float *pooled, int64_t ldp, const float *Wt, int64_t ldw, const float *bias, int B, int H, int C,
+                           float *logits, int64_t ldl, const float *overlap_partials, int F_block, float *xy, uint32_t *signal,
+                           ggcn_stream_t stream)
+{
+    if (!signal) return fail(GGCN_EINVAL, "ggcn_dense_head_signal: null signal words (ggcn_dense_head is the plain form)");
+    return dense_head(pooled, ldp, Wt, ldw, bias, B, H, C, logits, ldl, overlap_partials, F_block, xy, as_stream(stream), signal);
+}
+
 size_t ggcn_overlap_workspace_bytes(int B) { return overlap_workspace_bytes(B); }
 
 int ggcn_gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,

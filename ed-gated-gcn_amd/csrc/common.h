@@ -146,7 +146,7 @@ int scores_head(const float *X, int64_t ldx, const float *aspect, int64_t lda, c
                 int C, float *scores, int64_t lds_, float *kl_part, hipStream_t st);
 
 int dense_head(const float *pooled, int64_t ldp, const float *Wt, int64_t ldw, const float *bias, int B, int H, int C,
-               float *logits, int64_t ldl, const float *partials, int F_block, float *xy, hipStream_t st);
+               float *logits, int64_t ldl, const float *partials, int F_block, float *xy, hipStream_t st, unsigned *signal = nullptr);
 
 size_t overlap_workspace_bytes(int B);
 int gate_overlap(const float *x1, const float *y1, int B, int F, float *xy, void *workspace,

@@ -151,12 +151,30 @@ __global__ __launch_bounds__(256) void scores_head_kernel(const float *__restric
 // of the launch, when the caller passes them, adds the regulariser's partials of a ggcn_block_fused launch (bert_amir5.py:638)
 // in reduce_partials' order (fused_common.h) -- the one-workgroup ggcn_overlap_reduce launch rides along: at a 512-graph shard
 // the two tail launches were 13 us of a 95 us step, this one is ~4.
+// ggcn_dense_head_signal: the launch counts itself done in memory.  signal[0] collects the workgroups of this launch (every
+// workgroup's results are fenced before it arrives; the last arriver clears it for the next launch), signal[1] counts finished
+// launches -- a stream gated on it by hipStreamWaitValue32(>= n) may read the logits and xy of the n-th launch without an event
+// record on the launching stream (the sharded step: shard.PooledGather, `flag` hand-off).
+__device__ __forceinline__ void head_signal(unsigned *__restrict__ signal, int tid)
+{
+    if (!signal) return;   // kernel-uniform
+    __syncthreads();       // every store of this workgroup has been issued
+    if (tid == 0) {
+        __threadfence_system();
+        if (atomicAdd(signal, 1u) == gridDim.x - 1) {
+            signal[0] = 0u;
+            __threadfence_system();
+            atomicAdd_system(signal + 1, 1u);
+        }
+    }
+}
+
 constexpr int kHeadRows = 8, kHeadThreads = 1024, kHeadWaves = kHeadThreads / 64;
 static_assert(kHeadWaves == 2 * kHeadRows, "two wavefronts stage a pooled row");
 __global__ __launch_bounds__(kHeadThreads) void dense_head_kernel(const float *__restrict__ pooled, int64_t ldp, const float *__restrict__ Wt,
                                                                   int64_t ldw, const float *__restrict__ bias, int B, int H, int C,
                                                                   float *__restrict__ logits, int64_t ldl, const float *__restrict__ part,
-                                                                  int n_part, float *__restrict__ xy, int head_blocks)
+                                                                  int n_part, float *__restrict__ xy, int head_blocks, unsigned *__restrict__ signal)
 {
     extern __shared__ __attribute__((aligned(16))) float head_lds[];   // [kHeadRows][H] pooled rows, then [kHeadWaves][kHeadRows][64] partial sums
     const int tid = threadIdx.x, lane = tid & 63;
@@ -174,6 +192,7 @@ __global__ __launch_bounds__(kHeadThreads) void dense_head_kernel(const float *_
             for (int w = 0; w < kHeadWaves; ++w) t += head_lds[w];
             *xy = t / (float)B;
         }
+        head_signal(signal, tid);
         return;
     }
     const int b0 = blockIdx.x * kHeadRows;
@@ -226,6 +245,7 @@ __global__ __launch_bounds__(kHeadThreads) void dense_head_kernel(const float *_
         for (int w = 0; w < kHeadWaves; ++w) t += red[(w * kHeadRows + wave) * 64 + lane];
         logits[(int64_t)(b0 + wave) * ldl + lane] = t + (bias ? bias[lane] : 0.0f);
     }
+    head_signal(signal, tid);
 }
 
 }  // namespace
@@ -272,7 +292,7 @@ int scores_head(const float *X, int64_t ldx, const float *aspect, int64_t lda, c
 }
 
 int dense_head(const float *pooled, int64_t ldp, const float *Wt, int64_t ldw, const float *bias, int B, int H, int C,
-               float *logits, int64_t ldl, const float *partials, int F_block, float *xy, hipStream_t st)
+               float *logits, int64_t ldl, const float *partials, int F_block, float *xy, hipStream_t st, unsigned *signal)
 {
     if (!pooled || !Wt || !logits) return fail(GGCN_EINVAL, "ggcn_dense_head: null pointer");
     if ((partials != nullptr) != (xy != nullptr)) return fail(GGCN_EINVAL, "ggcn_dense_head: overlap_partials and xy go together");
@@ -283,7 +303,7 @@ int dense_head(const float *pooled, int64_t ldp, const float *Wt, int64_t ldw, c
     const size_t lds = ((size_t)kHeadRows * H + (size_t)kHeadWaves * kHeadRows * 64) * sizeof(float);
     if (lds > 64 * 1024) return fail(GGCN_EUNSUPPORTED, "ggcn_dense_head: H=%d needs more than 64 KiB of LDS", H);
     hipLaunchKernelGGL(dense_head_kernel, dim3((unsigned)(head_blocks + (partials ? 1 : 0))), dim3(kHeadThreads), lds, st, pooled, ldp, Wt, ldw, bias,
-                       B, H, C, logits, ldl, partials, partials ? B * ((F_block + 63) / 64) : 0, xy, head_blocks);
+                       B, H, C, logits, ldl, partials, partials ? B * ((F_block + 63) / 64) : 0, xy, head_blocks, signal);
     return check_launch("ggcn_dense_head");
 }
 

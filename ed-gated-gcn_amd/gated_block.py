@@ -148,15 +148,16 @@ def gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1=False, one_launch=
             raise RuntimeError("dense_head= is an inference feature; under autograd apply the classifier's own dense layer")
         r = _gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1, one_launch, want, _defer_xy=True)
         part = r.pop("_xy_partials", None)
+        sig = dense_head[2] if len(dense_head) > 2 else None   # (wt, bias[, signal words]): see heads.dense_head
         if r["out"] is None:
             raise RuntimeError("dense_head= needs `out` among want=")
         if r["out"].shape[0] == 0:
             r["logits"] = r["out"].new_zeros((0, dense_head[0].shape[1]))
             return r
         if part is not None:
-            r["logits"], r["xy"] = _dense_head(r["out"], dense_head[0], dense_head[1], partials=part, f_block=gc2.out_features)
+            r["logits"], r["xy"] = _dense_head(r["out"], dense_head[0], dense_head[1], partials=part, f_block=gc2.out_features, signal=sig)
         else:
-            r["logits"] = _dense_head(r["out"], dense_head[0], dense_head[1])
+            r["logits"] = _dense_head(r["out"], dense_head[0], dense_head[1], signal=sig)
         return r
     return _gated_gcn_block(x, adj, gate1, gate2, gc1, gc2, want_gcn1, one_launch, want)
 

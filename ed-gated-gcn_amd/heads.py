@@ -104,12 +104,13 @@ def scores_and_kl(x, aspect, logits, fc_linear, dist):
     return scores, kl
 
 
-def dense_head(pooled, wt, bias=None, partials=None, f_block=None):
+def dense_head(pooled, wt, bias=None, partials=None, f_block=None, signal=None):
     """``logits = pooled @ wt (+ bias)`` -- the share of ``bert_amir5.py:643``'s ``dense`` that reads the block's pooled
     output -- as ONE launch; with ``partials`` (the regulariser's per-graph partial sums of the one-launch block,
     ``bert_amir5.py:638``) the same launch also finishes ``xy``.  ``wt`` is ``[H, C]`` (the ``nn.Linear`` weight slice
     transposed), ``C <= 64``.  Returns ``logits`` or ``(logits, xy)``.  A row's logits are the same bits whatever batch or
-    shard the row sits in."""
+    shard the row sits in.  ``signal`` (two zeroed int32 words on the GPU): the launch counts itself done in ``signal[1]``
+    (``ggcn_dense_head_signal``), so that another stream can be gated on it without an event (``shard.PooledGather``)."""
     for name, t in (("pooled", pooled), ("wt", wt)):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
             raise RuntimeError("%s must be a float32 2-D GPU tensor with unit column stride (no CPU path exists)" % name)
@@ -124,7 +125,14 @@ def dense_head(pooled, wt, bias=None, partials=None, f_block=None):
     with torch.cuda.device(dev):
         logits = torch.empty(B, C, dtype=torch.float32, device=dev)
         xy = torch.empty((), dtype=torch.float32, device=dev) if partials is not None else None
-        _capi.check(lib.ggcn_dense_head(_capi.ptr(pooled), pooled.stride(0), _capi.ptr(wt), wt.stride(0), _capi.ptr(bias), B, H, C,
-                                        _capi.ptr(logits), C, _capi.ptr(partials), int(f_block or 0), _capi.ptr(xy),
-                                        _capi.stream_of(dev)), "ggcn_dense_head")
+        if signal is not None:
+            if not (signal.is_cuda and signal.dtype == torch.int32 and signal.numel() >= 2 and signal.is_contiguous()):
+                raise RuntimeError("signal must be a contiguous int32 GPU tensor of two words")
+            _capi.check(lib.ggcn_dense_head_signal(_capi.ptr(pooled), pooled.stride(0), _capi.ptr(wt), wt.stride(0), _capi.ptr(bias), B, H, C,
+                                                   _capi.ptr(logits), C, _capi.ptr(partials), int(f_block or 0), _capi.ptr(xy),
+                                                   _capi.ptr(signal), _capi.stream_of(dev)), "ggcn_dense_head_signal")
+        else:
+            _capi.check(lib.ggcn_dense_head(_capi.ptr(pooled), pooled.stride(0), _capi.ptr(wt), wt.stride(0), _capi.ptr(bias), B, H, C,
+                                            _capi.ptr(logits), C, _capi.ptr(partials), int(f_block or 0), _capi.ptr(xy),
+                                            _capi.stream_of(dev)), "ggcn_dense_head")
     return logits if partials is None else (logits, xy)

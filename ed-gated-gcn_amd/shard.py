@@ -6,6 +6,8 @@ weights are replicated, and the ONLY collective is one all-gather of the per-sha
 ``out [B_r, H]``.  ``torch.distributed`` backend "nccl" is RCCL on ROCm; the same code
 runs on "gloo" with CPU tensors (tests/test_shard_gloo.py).
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -61,35 +63,84 @@ class PooledGather:
             [torch.zeros(self.max_count, width, device=device, dtype=dtype) for _ in range(2)]
         self.inflight = [None, None]   # the last collective launched from each slot
         self.turn = 0
+        self.side = None               # the `flag` hand-off's stream (start(..., gate=))
 
-    def start(self, pooled):
+    def start(self, pooled, gate=None):
+        """Launch the all-gather of ``pooled``.  ``gate=(signal, n)``: the `flag` hand-off -- ``pooled`` is being written by a
+        launch that counts itself done in ``signal[1]`` (``heads.dense_head(..., signal=)``: the n-th launch on these words),
+        and the collective is issued from a SIDE stream that ``hipStreamWaitValue32`` holds until ``signal[1] >= n``: the
+        stream the step runs on records no event and waits for nothing (the event hand-off cost the sharded step ~20 us of
+        its ~110).  ``finish`` then waits on the HOST for the side stream's event."""
         slot = self.turn
         self.turn ^= 1
         prev = self.inflight[slot]
         if prev is not None:           # the slot's buffers are still the operands of that collective
-            prev.wait()
+            self._wait(prev)
         buf = self.bufs[slot]
-        src = pooled
+        if gate is not None:
+            signal, n = gate
+            side = self._side_stream(pooled.device)
+            rc = _hip().hipStreamWaitValue32(ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(signal.data_ptr() + 4),
+                                            ctypes.c_uint32(n & 0xFFFFFFFF), 0, 0xFFFFFFFF)   # 0 = hipStreamWaitValueGte
+            if rc != 0:
+                raise RuntimeError("hipStreamWaitValue32 failed (%d)" % rc)
+            with torch.cuda.stream(side):
+                src = self._source(pooled, slot)
+                work = dist.all_gather_into_tensor(buf, src, group=self.group, async_op=True)
+                work.wait()            # (the side stream waits for the collective; the host does not)
+                done = torch.cuda.Event()
+                done.record(side)
+            handle = (work, buf, src, done)
+        else:
+            src = self._source(pooled, slot)
+            work = dist.all_gather_into_tensor(buf, src, group=self.group, async_op=True)
+            handle = (work, buf, src)  # src is kept alive by the handle until finish()
+        self.inflight[slot] = handle
+        return handle
+
+    def _source(self, pooled, slot):
         if not self.uniform:  # pad to the largest shard so one fixed-size collective serves every rank
             pad = self.pads[slot]
             pad[:pooled.shape[0]].copy_(pooled)
-            src = pad
-        elif not src.is_contiguous():
-            src = src.contiguous()
-        work = dist.all_gather_into_tensor(buf, src, group=self.group, async_op=True)
-        self.inflight[slot] = work
-        return work, buf, src          # src is kept alive by the handle until finish()
+            return pad
+        return pooled if pooled.is_contiguous() else pooled.contiguous()
+
+    def _side_stream(self, device):
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=device)
+        return self.side
+
+    @staticmethod
+    def _wait(handle):
+        if len(handle) > 3:            # flag hand-off: the side stream's event, waited for on the host -- by polling: a sleeping
+            while not handle[3].query():   # hipEventSynchronize comes back tens of microseconds late, and the next replay with it
+                pass
+        else:
+            handle[0].wait()
 
     def finish(self, handle):
-        work, buf = handle[0], handle[1]
-        work.wait()
+        buf = handle[1]
+        self._wait(handle)
         for s in range(2):
-            if self.inflight[s] is work:
+            if self.inflight[s] is handle:
                 self.inflight[s] = None
         if self.uniform:
             return buf
         parts = [buf[r * self.max_count: r * self.max_count + c] for r, c in enumerate(self.counts)]
         return torch.cat(parts, dim=0)
+
+
+_HIP = []
+
+
+def _hip():
+    """libamdhip64 (already in the process: torch links it) for hipStreamWaitValue32, which torch does not expose."""
+    if not _HIP:
+        lib = ctypes.CDLL("libamdhip64.so")
+        lib.hipStreamWaitValue32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint, ctypes.c_uint32]
+        lib.hipStreamWaitValue32.restype = ctypes.c_int
+        _HIP.append(lib)
+    return _HIP[0]
 
 
 def sharded_forward(local_forward, counts, width, device, group=None):

@@ -410,6 +410,15 @@ int ggcn_overlap_reduce(const float *partials, int B, int F, float *xy, ggcn_str
 int ggcn_dense_head(const float *pooled, int64_t ldp, const float *Wt, int64_t ldw, const float *bias, int B, int H, int C,
                     float *logits, int64_t ldl, const float *overlap_partials, int F_block, float *xy, ggcn_stream_t stream);
 
+/* The same launch, counting itself done in memory: signal = two zero-initialised uint32 words in device memory; signal[1]
+ * becomes n once the n-th launch on these words has written (and fenced, system scope) all of its logits and xy -- another stream
+ * gated by hipStreamWaitValue32(signal + 1, >= n) may then read them, with no event record on the launching stream (the sharded
+ * step hands its logits to the collective's stream this way: ed-gated-gcn_amd/shard.py, bench.py --gather-mode flag).
+ * signal[0] is the launch's own arrival counter (zero between launches).  One launch at a time per pair of words. */
+int ggcn_dense_head_signal(const float *pooled, int64_t ldp, const float *Wt, int64_t ldw, const float *bias, int B, int H, int C,
+                           float *logits, int64_t ldl, const float *overlap_partials, int F_block, float *xy, uint32_t *signal,
+                           ggcn_stream_t stream);
+
 /* ---- gate-diversity regulariser --------------------------------------------
  * Replaces models/bert_amir5.py:638: *xy = mean_b sum_f x1[b,f]*y1[b,f].
  * x1,y1 [B,F] contiguous, xy one device float.  Deterministic (fixed-order

@@ -1680,10 +1680,20 @@ def test_dense_head_rides_with_the_regularisers_final_sum(pkg, dev, B, T, H, C):
     lo, hi = B // 3, max(B // 3 + 1, 2 * B // 3)
     sub = pkg.dense_head(plain["out"][lo:hi], wt, bias)
     assert torch.equal(sub, r["logits"][lo:hi])
+    # ggcn_dense_head_signal: the same launch counting itself done in memory (the sharded step's `flag` hand-off): same bits,
+    # signal[1] = number of finished launches, signal[0] (its arrival counter) back at zero
+    signal = torch.zeros(2, dtype=torch.int32, device=dev)
+    with torch.no_grad():
+        for n in (1, 2, 3):
+            rs = pkg.gated_gcn_block(x, adj, g1, g2, l1, l2, dense_head=(wt, bias, signal))
+            torch.cuda.synchronize()
+            assert signal.tolist() == [0, n]
+    assert torch.equal(rs["logits"], r["logits"]) and float(rs["xy"]) == float(r["xy"])
     lib = pkg.load_library()
     from ed_gated_gcn_amd import _capi
     P = _capi.ptr
     assert lib.ggcn_dense_head(P(plain["out"]), H, P(wt), C, None, B, H, C, P(r["logits"]), C, P(plain["out"]), H, None, _capi.stream_of(dev)) != 0   # partials without xy
+    assert lib.ggcn_dense_head_signal(P(plain["out"]), H, P(wt), C, None, B, H, C, P(r["logits"]), C, None, 0, None, None, _capi.stream_of(dev)) != 0   # no signal words
     big = torch.zeros(H, 65, device=dev)
     with pytest.raises(RuntimeError, match="at most 64"):
         pkg.dense_head(plain["out"], big)
@@ -1890,7 +1900,7 @@ def test_bench_self_launches_its_ranks_and_the_gathered_logits_match_the_unshard
     assert r["value"] > 0 and "roofline" in r
 
 
-@pytest.mark.parametrize("gather_mode", ["async", "graph"])
+@pytest.mark.parametrize("gather_mode", ["async", "flag", "graph"])
 def test_bench_distributed_loop_over_rccl_with_a_process_group_of_one(pkg, dev, gather_mode):
     """The only collective of the path (BASELINE configs[2]: all-gather of per-shard logits over xGMI) runs on RCCL, and the
     build box has one GPU: `bench.py --gpus 1 --force-dist --backend nccl` runs bench.py's N > 1 step loop -- RCCL process
