@@ -443,12 +443,8 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             lab_bm[j] = i32x8{w[0], w[1], w[2], w[3], bq[j][0], bq[j][1], bq[j][2], bq[j][3]};
         }
     }
-    // TAIL (the loop's last two stages when peeled, GGCN_LAB_PEEL): 1 = no stage st + 2 exists (its X loads are not issued), 2 = no
-    // stage st + 1 either (no W fragments asked for, nothing split or written): the plain loop clamps those stage numbers and does
-    // the work in vain -- 2 of 26 X stage loads, 1 of 25 W loads, 1 of 25 splits per workgroup
-    auto stage = [&](int st, auto bufc, auto tailc) {
+    auto stage = [&](int st, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        constexpr int TAIL = decltype(tailc)::value;
         const int k_next1 = kstage(st + 1) * BK;
         const int ka = kstage(st + 2) * BK;
         f16x8 ah[2][2];
@@ -472,16 +468,16 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[0], acc[i][0], 0, 0, 0);
             GGCN_SB();
-            if GGCN_ON(2) { if (TAIL < 2 && i - SLOT0 >= 0 && i - SLOT0 < NP && i - SLOT0 < GGCN_LAB_XPASSES && i - SLOT0 < XP) split_pass(i - SLOT0, k_next1); }
+            if GGCN_ON(2) { if (i - SLOT0 >= 0 && i - SLOT0 < NP && i - SLOT0 < GGCN_LAB_XPASSES && i - SLOT0 < XP) split_pass(i - SLOT0, k_next1); }
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][0], b0[1], acc[i][1], 0, 0, 0);
             GGCN_SB();
-            if GGCN_ON(4) { if (TAIL < 2 && i - SLOT0 >= 0 && i - SLOT0 < NP && i - SLOT0 < GGCN_LAB_XPASSES && i - SLOT0 < XP) write_pass(buf ^ 1, i - SLOT0); }
+            if GGCN_ON(4) { if (i - SLOT0 >= 0 && i - SLOT0 < NP && i - SLOT0 < GGCN_LAB_XPASSES && i - SLOT0 < XP) write_pass(buf ^ 1, i - SLOT0); }
             else { _Pragma("unroll") for (int q = 0; q < NQ; ++q) asm volatile("" :: "v"(sp[q].h01), "v"(sp[q].h23), "v"(sp[q].l8), "v"(sp[q].h8)); }
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[0], acc[i][0], 0, 0, 0);
             GGCN_SB();
-            if GGCN_ON(1) { if (TAIL < 1 && i - SLOT0 >= 0 && i - SLOT0 < NP && i - SLOT0 < GGCN_LAB_XPASSES && i - SLOT0 < XP) load_a_pass(i - SLOT0, ka); }
+            if GGCN_ON(1) { if (i - SLOT0 >= 0 && i - SLOT0 < NP && i - SLOT0 < GGCN_LAB_XPASSES && i - SLOT0 < XP) load_a_pass(i - SLOT0, ka); }
             else { if (i < NP) { _Pragma("unroll") for (int c = 0; c < EPT; ++c) asm volatile("" : "+v"(ra[i][c])); } }
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i & 1][1], b1[1], acc[i][1], 0, 0, 0);
@@ -512,7 +508,7 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
             if (!RBLK || i < nblk) acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[0], acc[i][0], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[0]);
             GGCN_SB();
             if constexpr (GGCN_LAB_WH8) { if (i == 0) make_bm(1); }
-            if constexpr (!W2) { if GGCN_ON(16) { if (TAIL < 2 && i == 0) load_bf(kstage(st + 1), b0, b1); } }  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
+            if constexpr (!W2) { if GGCN_ON(16) { if (i == 0) load_bf(kstage(st + 1), b0, b1); } }  // b0/b1 are dead: the fp16 MFMAs of this stage are all issued
             GGCN_SB();
             if (!RBLK || i < nblk) acc[i][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i & 1], bm[1], acc[i][1], GGCN_LAB_MXFMT, GGCN_LAB_MXFMT, 0, scale_a, 0, sq[1]);
             GGCN_SB();
@@ -520,24 +516,11 @@ __device__ __forceinline__ void mainloop(const AT *const (&arow)[Geom<AT>::NP], 
         if GGCN_ON(64) __syncthreads();
     };
     int st = 0;
-    using T0 = std::integral_constant<int, 0>;
-    using T1 = std::integral_constant<int, 1>;
-    using T2 = std::integral_constant<int, 2>;
-    constexpr bool PEEL = (GGCN_LAB_PEEL) != 0 && (GGCN_LAB_OFF) == 0 && !W2;
-    if (PEEL && stages >= 4 && (stages & 1) == 0) {   // (workgroup-uniform) an even number of stages: the last two are their own code
-        for (; st + 2 < stages; st += 2) {
-            stage(st, T0{}, T0{});
-            stage(st + 1, T1{}, T0{});
-        }
-        stage(st, T0{}, T1{});
-        stage(st + 1, T1{}, T2{});
-    } else {
-        for (; st + 1 < stages; st += 2) {
-            stage(st, T0{}, T0{});
-            stage(st + 1, T1{}, T0{});
-        }
-        if (st < stages) stage(st, T0{}, T0{});
+    for (; st + 1 < stages; st += 2) {
+        stage(st, std::integral_constant<int, 0>{});
+        stage(st + 1, std::integral_constant<int, 1>{});
     }
+    if (st < stages) stage(st, std::integral_constant<int, 0>{});
     set_cvt_saturate(false);
     if (amax_out) *amax_out = amax;   // the caller adds its own bound to the verdict (fused_layer.hip)
     else range_verdict(amax);

@@ -31,9 +31,6 @@
 #ifndef GGCN_LAB_OFF
 #define GGCN_LAB_OFF 0
 #endif
-#ifndef GGCN_LAB_PEEL
-#define GGCN_LAB_PEEL 0   // 1: the f16mx8 main loop's last two stages are separate code without the loads / splits of stages that do not exist
-#endif
 #ifndef GGCN_LAB_NO_DMA_STAGE
 #define GGCN_LAB_NO_DMA_STAGE 0   // 1: the 32-node kernel stages its epilogue operands through registers as before round 5 (A/B switch)
 #endif
