@@ -261,6 +261,151 @@ __global__ __launch_bounds__(kThreads, 2) void dweight_tn_kernel(const float *__
     }
 }
 
+// ---- the 256 x 256 tile: one workgroup of four wavefronts per CU, each with a 128 x 128 share = 256 accumulator registers (AGPRs)
+// of its 512 ----------------------------------------------------------------------------------------------------------
+// dweight_tn_kernel runs at the board's power cap (1400 W: its time is its energy), and a large term of that energy is what it
+// stages: per node row the 768 X features are brought into an LDS by the 3 column-group tiles and the 768 gradient values by the 6
+// row-group tiles -- 3.6 GB per launch at config 2.  A 256 x 256 tile stages [16][256] of both operands per 16 nodes for twice the
+// output area: a third less.  Same plane images, same transposed reads, the same products in the same order per output element
+// and the same chunks of the node axis as the 128 x 256 kernel: bit-identical results.
+constexpr int T2_B = 256;
+constexpr int kT2Buf = 8 * kPlaneX;          // X: 2 images x (hi, lo), dH: 2 images x (hi, lo) = 32 KiB
+constexpr int kT2Lds = 2 * kT2Buf;           // 64 KiB
+
+__global__ __launch_bounds__(kThreads, 1) void dweight_tn256_kernel(const float *__restrict__ X, int64_t ldx,
+                                                                    const float *__restrict__ G, int64_t ldg, int64_t N, int K, int F,
+                                                                    float *__restrict__ slabs, int64_t chunk_rows, int n_splits,
+                                                                    int m_tiles, int n_wg)
+{
+    __shared__ __attribute__((aligned(16))) char lds[kT2Lds];
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int tiles = m_tiles * n_wg;
+    const int total = n_splits * tiles, per_xcd = (total + 7) >> 3;
+    const int w = xcd * per_xcd + qb;
+    if (qb >= per_xcd || w >= total) return;  // whole workgroup, before any barrier
+    const int split = w / tiles, tile = w - split * tiles;
+    const int m_tile = tile / n_wg, n_wgi = tile % n_wg;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = m_tile * T2_B, n0 = n_wgi * T2_B;
+    const int64_t row0 = (int64_t)split * chunk_rows;
+    const int64_t rows_end = row0 + chunk_rows < N ? row0 + chunk_rows : N;
+    const int stages = (int)((chunk_rows + TN_NODES - 1) / TN_NODES);
+
+    // staging: both tiles are [16 nodes][256 columns] fp32 = 1024 pieces of 16 B, 4 per thread: node = idx / 64, column = 4 (idx % 64)
+    int pnode[4], pcol[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { const int idx = tid + 256 * p; pnode[p] = idx >> 6; pcol[p] = (idx & 63) * 4; }
+    float4 rx[4], rg[4];
+    constexpr int kRsrcFlags = 0x00020000;
+    const int64_t rows_here = rows_end > row0 ? rows_end - row0 : 0;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + row0 * ldx), 0, (int)(rows_here * ldx * 4), kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(G + row0 * ldg), 0, (int)(rows_here * ldg * 4), kRsrcFlags);
+    uint32_t xoff[4], goff[4];
+    int po[4];     // LDS offset of piece p inside its operand's half of a buffer
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        xoff[p] = (uint32_t)(((int64_t)pnode[p] * ldx + m0 + pcol[p]) * 4);
+        goff[p] = (uint32_t)(((int64_t)pnode[p] * ldg + n0 + pcol[p]) * 4);
+        po[p] = (pcol[p] >> 7) * 2 * kPlaneX + tn_off(pnode[p], (pcol[p] & 127) >> 3) + (pcol[p] & 4) * 2;
+    }
+    const uint32_t xstep = (uint32_t)(TN_NODES * ldx * 4), gstep = (uint32_t)(TN_NODES * ldg * 4);
+    auto load_x = [&](int s, int p) { rx[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[p], (uint32_t)s * xstep, 0)); };
+    auto load_g = [&](int s, int p) { rg[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, goff[p], (uint32_t)s * gstep, 0)); };
+    auto write_x = [&](int s, int p) {
+        char *b = lds + (s & 1) * kT2Buf;
+        bf16x4 hi, lo;
+        split_bf16x4(rx[p], hi, lo);
+        *reinterpret_cast<bf16x4 *>(b + po[p]) = hi;
+        *reinterpret_cast<bf16x4 *>(b + kPlaneX + po[p]) = lo;
+    };
+    auto write_g = [&](int s, int p) {
+        char *b = lds + (s & 1) * kT2Buf + 4 * kPlaneX;
+        bf16x4 hi, lo;
+        split_bf16x4(rg[p], hi, lo);
+        *reinterpret_cast<bf16x4 *>(b + po[p]) = hi;
+        *reinterpret_cast<bf16x4 *>(b + kPlaneX + po[p]) = lo;
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // A = the X image of this wavefront's 128 features (image wr), block i; B = the dH image wc, block j
+    int aoff[4][2], boff[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            aoff[i][hf] = wr * 2 * kPlaneX + tr_lane_off(i, hf, lane);
+            boff[i][hf] = 4 * kPlaneX + wc * 2 * kPlaneX + tr_lane_off(i, hf, lane);
+        }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { load_x(0, p); load_g(0, p); }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { write_x(0, p); write_g(0, p); }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { load_x(1, p); load_g(1, p); }   // (past the chunk: zeros)
+    __syncthreads();
+#define GGCN_SBT() __builtin_amdgcn_sched_barrier(0)
+    for (int s = 0; s < stages; ++s) {
+        const unsigned lb = (unsigned)(size_t)(lds + (s & 1) * kT2Buf);
+        bf16x8 bh[4], bl[4], ah[2], al[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tr_fragments(lb + boff[j][0], lb + boff[j][1], bh[j], bl[j]);
+        tr_fragments(lb + aoff[0][0], lb + aoff[0][1], ah[0], al[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(bh[j])); asm volatile("" : "+v"(bl[j])); }
+        asm volatile("" : "+v"(ah[0]));
+        asm volatile("" : "+v"(al[0]));
+        GGCN_SBT();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < 3) tr_fragments(lb + aoff[i + 1][0], lb + aoff[i + 1][1], ah[(i + 1) & 1], al[(i + 1) & 1]);
+            GGCN_SBT();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);   // small terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
+                GGCN_SBT();
+                // a share of the next stage's split + LDS writes (the other buffer) and of the loads two stages ahead per MFMA group
+                if (j == 0) write_x(s + 1, i);
+                if (j == 1) write_g(s + 1, i);
+                GGCN_SBT();
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+                GGCN_SBT();
+                if (j == 2) load_x(s + 2, i);
+                if (j == 3) load_g(s + 2, i);
+                GGCN_SBT();
+            }
+            if (i < 3) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(ah[(i + 1) & 1]));
+                asm volatile("" : "+v"(al[(i + 1) & 1]));
+            }
+        }
+        __syncthreads();
+    }
+#undef GGCN_SBT
+    float *slab = slabs + (int64_t)split * K * F;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gn = n0 + 128 * wc + 32 * j + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gmb = m0 + 128 * wr + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(int64_t)(gmb + (r & 3) + 8 * (r >> 2)) * F + gn] = acc[i][j][r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tn_slab_sum_kernel(const float *__restrict__ slabs, int n_slabs, int64_t kf, int F,
                                                          float *__restrict__ dW, int64_t lddw)
 {
@@ -271,15 +416,29 @@ __global__ __launch_bounds__(256) void tn_slab_sum_kernel(const float *__restric
     dW[(i / F) * lddw + (i % F)] = s;
 }
 
-struct TnPlan { int m_tiles, n_wg, n_splits; int64_t chunk_rows; size_t slab_bytes; };
+struct TnPlan { int m_tiles, n_wg, n_splits; int64_t chunk_rows; size_t slab_bytes; bool big; };
+
+// The 256 x 256 tile where it pays: whole tiles (K, F multiples of 256) and enough node rows that one workgroup per CU still gets
+// chunks of a thousand rows and more (131 072 x 768 x 768: 0.600 J against 0.638 J per launch, each alone at the 1400 W cap: 429 vs
+// 456 us; the training step 2.89-2.91 vs 2.93-2.98 ms; 20 000 rows: 98 vs 96 us, 5 000 x 256 x 512: 49 vs 36 us -- those keep the
+// 128 x 256 tile).  A pure function of the shape: ggcn_dweight_workspace_bytes and ggcn_dweight can never disagree.
+bool tn_big_tile(int64_t N, int K, int F)
+{
+    bool big = K % T2_B == 0 && F % T2_B == 0 && N >= 65536;
+#ifdef GGCN_LAB_DW   // lab builds only (tools/labbuild.sh "-DGGCN_LAB_DW"): GGCN_DW_TILE=128 / 256 picks the tile per call
+    if (const char *e = getenv("GGCN_DW_TILE")) big = K % T2_B == 0 && F % T2_B == 0 && atoi(e) == 256;
+#endif
+    return big;
+}
 
 TnPlan tn_plan(int64_t N, int K, int F)
 {
     TnPlan p;
-    p.m_tiles = (K + TN_BM - 1) / TN_BM;
-    p.n_wg = (F + TN_BN - 1) / TN_BN;
+    p.big = tn_big_tile(N, K, F);
+    p.m_tiles = p.big ? K / T2_B : (K + TN_BM - 1) / TN_BM;
+    p.n_wg = p.big ? F / T2_B : (F + TN_BN - 1) / TN_BN;
     const int tiles = p.m_tiles * p.n_wg;
-    int64_t s = 512 / tiles;           // as many chunks as fill the chip's 512 resident slots (two workgroups per CU) in ONE round
+    int64_t s = (p.big ? 256 : 512) / tiles;   // as many chunks as fill the chip's resident slots (two 128 x 256 workgroups per CU, or one 256 x 256) in ONE round
     if (s < 8) s = 8;                  // (more tiles than slots: eight chunks, several rounds)
     const int64_t max_s = (N + 511) / 512;   // at least 512 node rows per chunk
     if (s > max_s) s = max_s;
@@ -323,7 +482,10 @@ int dweight_tn(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t
     if ((p.chunk_rows + TN_NODES) * (ldx > ldg ? ldx : ldg) * 4 >= ((int64_t)1 << 31))
         return fail(GGCN_EUNSUPPORTED, "ggcn_dweight: a chunk of %lld rows of %lld floats exceeds the 2 GiB a buffer resource addresses",
                     (long long)p.chunk_rows, (long long)(ldx > ldg ? ldx : ldg));
-    if (K % TN_BM == 0 && F % TN_BN == 0)
+    if (p.big)
+        hipLaunchKernelGGL(dweight_tn256_kernel, dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, G, ldg, N, K, F, slabs,
+                           p.chunk_rows, p.n_splits, p.m_tiles, p.n_wg);
+    else if (K % TN_BM == 0 && F % TN_BN == 0)
         hipLaunchKernelGGL(dweight_tn_kernel<true>, dim3((unsigned)grid), dim3(kThreads), 0, st, X, ldx, G, ldg, N, K, F, slabs,
                            p.chunk_rows, p.n_splits, p.m_tiles, p.n_wg);
     else
