@@ -967,10 +967,11 @@ def test_regulariser_folded_into_the_layer_launches(pkg, dev, B, T, H, precision
 
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("N,K,F", [(20000, 768, 768), (5000, 132, 260), (37, 8, 12), (513, 256, 34), (1, 4, 4),
-                                   (301, 7, 9), (64, 33, 2)])
+                                   (301, 7, 9), (64, 33, 2), (70001, 256, 512)])
 def test_weight_gradient_vs_float64(pkg, dev, precision, N, K, F):
     """dW = X^T . dH (backward of gcn.py:34) through the C ABI, both forms, against float64; twice for
-    bitwise reproducibility (fixed-order slab sums, no atomics)."""
+    bitwise reproducibility (fixed-order slab sums, no atomics).  (70001 x 256 x 512: whole 256-column tiles from 65 536 rows up
+    take the 256 x 256 tile of the TN form, one workgroup per CU; a row count that is no multiple of anything.)"""
     from ed_gated_gcn_amd import _capi
     lib = pkg.load_library()
     rng = np.random.default_rng(N + K)
@@ -989,6 +990,8 @@ def test_weight_gradient_vs_float64(pkg, dev, precision, N, K, F):
     assert np.array_equal(outs[0], outs[1])
     scale = np.sqrt(N) * 1e-3
     bound = {"fp32": 2e-6, "bf16x3": 3e-5}[precision] * max(scale, 1e-3)
+    if precision == "fp32" and N > 50000:
+        bound *= 2.0     # (fp32 chains three times as long as the shapes the bound was set on)
     assert np.max(np.abs(outs[0] - ref)) <= bound
     rc = lib.ggcn_dweight(_capi.ptr(xd), K, _capi.ptr(gd), F, N, K, F, _capi.ptr(dw), F, _capi.PREC["f16mx8"],
                           _capi.ptr(ws), _capi.stream_of(dev))
