@@ -53,12 +53,17 @@ class _GatedLayerFunction(torch.autograd.Function):
         ctx.layer, ctx.csr, ctx.dropout = layer, csr, dropout
         ctx.save_for_backward(text, weight, out, store_gate, gate_a, gate_b)
         ctx.has_bias = bias is not None
+        # an output the loss does not use arrives as None, not as a tensor of zeros: the [B,T,F] `out` of a layer whose pools alone
+        # are used would otherwise cost a 400 MB fill AND a 400 MB read per step (every backward kernel takes d_out = NULL)
+        ctx.set_materialize_grads(False)
         return out, pa, pb
 
     @staticmethod
     def backward(ctx, d_out, d_pa, d_pb):
         text, weight, out, store_gate, gate_a, gate_b = ctx.saved_tensors
         layer, csr = ctx.layer, ctx.csr
+        if d_out is None and d_pa is None and d_pb is None:
+            return (None,) * 11
         lib = _capi.load_library()
         B, T, K = text.shape
         F = layer.out_features
