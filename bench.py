@@ -886,8 +886,12 @@ def main():
     roofline = None
     if "ggcn_block_fused" in kern_us:
         t = statistics.mean(kern_us["ggcn_block_fused"])
-        roofline = mfma_line("layer_fused_kernel (block form: both layers of the block in one launch)",
-                             "block_fused_kernel:" + args.precision, t, 2 * (lin_flops + agg_flops), fwd_bytes,
+        # (ggcn_block_fused runs batches of >= 2048 graphs on the eight-wavefront workgroup that stages a row block's X planes once
+        # for a W1 and a W12 column slice -- fused_block8.hip; GGCN_BLOCK_FORM=4 keeps the four-wavefront kernel)
+        form8 = (args.precision == "f16mx8" and B >= 2048 and H % 256 == 0 and os.environ.get("GGCN_BLOCK_FORM", "8")[:1] != "4")
+        roofline = mfma_line("block_fused8_kernel (both layers of the block in one launch; eight wavefronts share a row block's X planes)" if form8 else
+                             "layer_fused_kernel (block form: both layers of the block in one launch)",
+                             ("block_fused8_kernel:" if form8 else "block_fused_kernel:") + args.precision, t, 2 * (lin_flops + agg_flops), fwd_bytes,
                              "one launch per step = 2 layers: 2 x (2*N*K*F + 2*nnz*F) flops, 2 x SURVEY 8(d) bytes")
         # what THIS kernel has to move: X in, x out, three pools, two gates, the graphs' operand blocks and the two packed
         # weight images -- SURVEY 8(d)'s figure still holds gcn1's write + read (2 x N*H*4), which the folded block never makes
@@ -897,7 +901,8 @@ def main():
             roofline["traffic_over_kernel_bytes"] = roofline["traffic"] / own
         roofline["note"] += ("; compare `traffic` with kernel_bytes_per_launch (X + x + pools + gates + operand blocks + W: what "
                              "the one-launch block must move), not with algorithmic_bytes_per_launch: the excess is X read "
-                             "by both XCD groups and by three column tiles each through 4 MiB L2s")
+                             + ("by three column slices through a 4 MiB L2 that also holds both weight images" if form8 else
+                                "by both XCD groups and by three column tiles each through 4 MiB L2s"))
     elif "ggcn_layer_fused_h" in kern_us:
         t = statistics.mean(kern_us["ggcn_layer_fused_h"])
         roofline = mfma_line("layer_fused_long_kernel (fp16 linear + LDS neighbour sums, one launch per layer)",

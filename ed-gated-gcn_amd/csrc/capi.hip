@@ -2,6 +2,7 @@
 // Argument checking lives here and in the per-kernel launchers; nothing in this
 // library allocates, frees, copies to the host or synchronises.
 #include "common.h"
+#include <cstdlib>
 #include "dropout_hash.h"
 
 #include <cstring>
@@ -261,8 +262,10 @@ int ggcn_lab_block_fused8(const float *X, int64_t ldx, const void *wpack1, const
                           const float *gate1, const float *gate2, float *x_out, int64_t ld2, float *x1, float *y1, float *pool_out,
                           float *overlap_partial, uint64_t *stamps, ggcn_stream_t stream)
 {
+    const int flags = (getenv("GGCN_LAB_BLOCK8_ROWMAJOR") ? kBlock8RowMajor : 0) | (getenv("GGCN_LAB_BLOCK8_NODMA") ? kBlock8NoDma : 0) |
+                      (getenv("GGCN_LAB_BLOCK8_SAMESLOTS") ? kBlock8SameSlots : 0);   // (the experiment's switches, read per call)
     return lab_block_fused8(X, ldx, wpack1, wpack12, graph_ops, graph_ops2, bias1, bias_mid, bias2, B, T, K, F, gate1, gate2, x_out, ld2,
-                            x1, y1, pool_out, overlap_partial, as_stream(stream), reinterpret_cast<unsigned long long *>(stamps));
+                            x1, y1, pool_out, overlap_partial, as_stream(stream), reinterpret_cast<unsigned long long *>(stamps), flags);
 }
 
 int ggcn_rowmask_transpose(const uint32_t *rowmask, int B, int T, uint32_t *rowmask_t, ggcn_stream_t stream)

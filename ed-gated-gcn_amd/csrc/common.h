@@ -130,11 +130,14 @@ int range_flag_linear(unsigned int *dst, int clear, hipStream_t st);   // linear
 int range_flag_fused(unsigned int *dst, int clear, hipStream_t st);    // fused_layer.hip
 int range_flag_wide(unsigned int *dst, int clear, hipStream_t st);     // fused_wide.hip
 int range_flag_wide8(unsigned int *dst, int clear, hipStream_t st);    // fused_wide8.hip
-int range_flag_block8(unsigned int *dst, int clear, hipStream_t st);   // fused_block8.hip (experiment)
+int range_flag_block8(unsigned int *dst, int clear, hipStream_t st);   // fused_block8.hip
 int lab_block_fused8(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops, const void *graph_ops2,
                      const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F, const float *gate1,
                      const float *gate2, float *x_out, int64_t ld2, float *x1, float *y1, float *pool_out, float *overlap_partial,
-                     hipStream_t st, unsigned long long *stamps = nullptr);
+                     hipStream_t st, unsigned long long *stamps = nullptr, int flags = 0);
+constexpr int kBlock8RowMajor = 1, kBlock8NoDma = 2, kBlock8SameSlots = 4, kBlock8Product = 8;
+bool block8_takes(const float *X, int64_t ldx, int B, int T, int K, int F, const float *gate1, const float *gate2, const float *bias1,
+                  const float *bias_mid, const float *bias2, const void *graph_ops, const void *graph_ops2, const float *x_out, int64_t ld2);
 int range_flag_fused6(unsigned int *dst, int clear, hipStream_t st);   // fused6.hip (GGCN_WITH_F16MX6)
 
 int transpose_f32(const float *W, int rows, int cols, int64_t ldw, float *Wt, hipStream_t st);

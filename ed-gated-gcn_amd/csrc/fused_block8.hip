@@ -104,12 +104,34 @@ __global__ __launch_bounds__(kB8Threads, 1) void block_fused8_kernel(const Fused
 
 }  // namespace
 
+// What ggcn_block_fused hands to this kernel (fused_layer.hip): the whole block with all of its outputs, f16mx8, on batches of at
+// least kBlock8MinGraphs graphs -- 6 and more rounds of one eight-wavefront workgroup per CU.  There, with the board at its power
+// cap, the X planes staged once for a W1 and a W12 column slice are worth 2 % of the launch IN STEADY STATE (each form alone for
+// 1.5 s: 603-604 vs 615-618 us at 4096 graphs on two boxes, 639 vs 653 on a slower one, 304-309 vs 313 at 2048; 512 graphs: 85 vs
+// 80 us, so shards keep the four-wavefront kernel) -- while five-launch interleaved timings had shown it 3-6 % SLOWER:
+// the power controller averages over milliseconds, and the benchmark's timed region is a steady state.
+constexpr int kBlock8MinGraphs = 2048;
+bool block8_takes(const float *X, int64_t ldx, int B, int T, int K, int F, const float *gate1, const float *gate2, const float *bias1,
+                  const float *bias_mid, const float *bias2, const void *graph_ops, const void *graph_ops2, const float *x_out, int64_t ld2)
+{
+    if (B < kBlock8MinGraphs || T > 32 || T <= 0 || F % BN != 0 || K % BK != 0) return false;
+    if (!((ldx % 4 == 0) && aligned16(X) && (int64_t)ldx * 4 * 257 < ((int64_t)1 << 31))) return false;
+    if (!graph_ops || !graph_ops2 || !gate1 || !gate2 || !bias_mid) return false;
+    if (!(aligned16(gate1) && aligned16(gate2) && aligned16(bias1) && aligned16(bias2) && aligned16(bias_mid) && aligned16(graph_ops) &&
+          aligned16(graph_ops2)))
+        return false;   // (the LDS-DMA staging of the epilogue's operands: the form that was measured)
+    if (x_out && !((ld2 % 4 == 0) && aligned16(x_out) && (int64_t)T * ld2 * 4 < ((int64_t)1 << 31))) return false;
+    return true;
+}
+
 int lab_block_fused8(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops, const void *graph_ops2,
                      const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F, const float *gate1,
                      const float *gate2, float *x_out, int64_t ld2, float *x1, float *y1, float *pool_out, float *overlap_partial,
-                     hipStream_t st, unsigned long long *stamps)
+                     hipStream_t st, unsigned long long *stamps, int flags)
 {
-    const char *who = "ggcn_lab_block_fused8";
+    // flags (common.h kBlock8*): ROWMAJOR = a row block's three column slices on one XCD (the product's map: ggcn_block_fused takes
+    // this kernel for large batches), else column slices pinned to XCDs; NODMA / SAMESLOTS: lab switches of ggcn_lab_block_fused8
+    const char *who = (flags & kBlock8Product) ? "ggcn_block_fused" : "ggcn_lab_block_fused8";
     if (!X || !wpack1 || !wpack12 || !graph_ops || !graph_ops2 || !gate1 || !gate2 || !x1 || !y1 || !bias_mid)
         return fail(GGCN_EINVAL, "%s: null pointer", who);
     if (B <= 0 || T <= 0 || T > 32 || K <= 0 || F <= 0) return fail(GGCN_EUNSUPPORTED, "%s: B=%d T=%d K=%d F=%d (graphs of <= 32 nodes)", who, B, T, K, F);
@@ -118,7 +140,7 @@ int lab_block_fused8(const float *X, int64_t ldx, const void *wpack1, const void
     if (!x_out && !pool_out) return fail(GGCN_EINVAL, "%s: neither x nor its pool requested", who);
     FusedArgs a = {};
     a.X = X; a.ldx = ldx; a.graph_ops = static_cast<const char *>(graph_ops); a.graph_ops2 = static_cast<const char *>(graph_ops2);
-    const bool rowmajor = getenv("GGCN_LAB_BLOCK8_ROWMAJOR") != nullptr;   // (experiment only)
+    const bool rowmajor = (flags & kBlock8RowMajor) != 0;
     a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = rowmajor ? 3 : 2;
     a.part[0] = LayerPart{static_cast<const char *>(wpack1), bias1, nullptr, nullptr, nullptr, gate1, gate2, nullptr, x1, y1, overlap_partial, 0};
     a.part[1] = LayerPart{static_cast<const char *>(wpack12), bias2, bias_mid, nullptr, gate2, gate2, nullptr, x_out, pool_out, nullptr, nullptr, (int)ld2};
@@ -126,9 +148,9 @@ int lab_block_fused8(const float *X, int64_t ldx, const void *wpack1, const void
     a.k_steps = round_up(K, BK) / KSTEP;
     // (bit 30 of k_steps: every gate / bias row this launch reads starts 16-byte aligned -- the LDS-DMA staging may be used)
     const bool al = (F % 4 == 0) && aligned16(gate1) && aligned16(gate2) && aligned16(bias1) && aligned16(bias2) && aligned16(bias_mid) &&
-                    aligned16(graph_ops) && aligned16(graph_ops2) && !getenv("GGCN_LAB_BLOCK8_NODMA");
+                    aligned16(graph_ops) && aligned16(graph_ops2) && !(flags & kBlock8NoDma);
     if (al) a.k_steps |= 0x40000000;
-    if (getenv("GGCN_LAB_BLOCK8_SAMESLOTS")) a.k_steps |= 0x20000000;
+    if (flags & kBlock8SameSlots) a.k_steps |= 0x20000000;
     a.n_wg = (F + BN - 1) / BN;
     a.g_tiles = (B + 3) / 4;
     const bool vst = x_out && (F % 4 == 0) && (ld2 % 4 == 0) && aligned16(x_out) && (int64_t)T * ld2 * 4 < ((int64_t)1 << 31);

@@ -37,6 +37,8 @@
 // pooled); T > 32 or weighted adjacency -> the unfused path (linear + aggregate.hip).
 #include "fused_common.h"
 
+#include <cstdlib>
+
 namespace ggcn {
 namespace {
 
@@ -611,6 +613,16 @@ int block_fused(const float *X, int64_t ldx, const void *wpack1, const void *wpa
     FusedArgs a = {};
     if (!graph_ops2 || !aligned16(graph_ops2))
         return fail(GGCN_EINVAL, "ggcn_block_fused: graph_ops2 (ggcn_graph_operands2 blocks, 16-byte aligned) is required");
+    // large batches, every output, f16mx8: the eight-wavefront workgroup that stages a row block's X planes once for a W1 and a W12
+    // column slice (fused_block8.hip: bit-identical results, 2 % less time in steady state from 2048 graphs up).
+    // GGCN_BLOCK_FORM=4 (read per call) keeps the four-wavefront kernel: A/B timing, tests.
+    if (layer1 && !gcn1 && !stamps && precision == GGCN_PREC_F16MX8 && X && wpack1 && wpack12 && bias_mid &&
+        block8_takes(X, ldx, B, T, K, F, gate1, gate2, bias1, bias_mid, bias2, graph_ops, graph_ops2, x_out, ld2)) {
+        const char *form = getenv("GGCN_BLOCK_FORM");
+        if (!(form && form[0] == '4'))
+            return lab_block_fused8(X, ldx, wpack1, wpack12, graph_ops, graph_ops2, bias1, bias_mid, bias2, B, T, K, F, gate1, gate2, x_out,
+                                    ld2, x1, y1, pool_out, overlap_partial, st, nullptr, kBlock8RowMajor | kBlock8Product);
+    }
     a.X = X; a.ldx = ldx; a.graph_ops = static_cast<const char *>(graph_ops); a.graph_ops2 = static_cast<const char *>(graph_ops2);
     a.B = B; a.T = T; a.K = K; a.F = F; a.n_parts = layer1 ? 2 : 1;
     a.stamps = stamps;

@@ -1751,7 +1751,7 @@ def test_precomputed_edge_lists_of_the_eight_wavefront_layer(pkg, dev, B, T, F):
 @pytest.mark.parametrize("B,T,H", [(16, 32, 256), (37, 23, 256), (5, 32, 768), (3, 7, 64)])
 def test_eight_wavefront_shared_x_experiment_is_bit_identical_to_the_block(pkg, dev, B, T, H):
     """ggcn_lab_block_fused8 (one workgroup of eight wavefronts shares a row block's X planes between its W1
-    and W12 column tiles; an experiment nothing in the product calls): the same tiles, arithmetic and order as ggcn_block_fused,
+    and W12 column tiles; since late round 5 also what ggcn_block_fused runs for batches of >= 2048 graphs): the same tiles, arithmetic and order as the four-wavefront kernel,
     so x, x1, y1, out and the regulariser's partials are the same bits -- whole and ragged batches, both XCD mappings, with and
     without the [N,F] output."""
     from ed_gated_gcn_amd import _capi, synth
@@ -1792,6 +1792,39 @@ def test_eight_wavefront_shared_x_experiment_is_bit_identical_to_the_block(pkg, 
                     assert bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all()), (k, rowmajor, with_x)
         finally:
             os.environ.pop("GGCN_LAB_BLOCK8_ROWMAJOR", None)
+
+
+@pytest.mark.parametrize("B,T,H", [(2048, 32, 256), (2100, 29, 256)])
+def test_large_batches_take_the_eight_wavefront_block_and_nothing_changes(pkg, dev, B, T, H):
+    """ggcn_block_fused hands batches of >= 2048 graphs (all outputs, f16mx8, whole 256-column groups) to the eight-wavefront
+    kernel of fused_block8.hip (2 % less time in steady state at the power cap); GGCN_BLOCK_FORM=4 keeps the four-wavefront
+    kernel.  Same tiles, same arithmetic, same order: every output the same bits, whole and ragged batches; against the oracle on
+    a slice; smaller batches, the eval form and a request for gcn1 stay where they were."""
+    from ed_gated_gcn_amd import synth
+    rng = np.random.default_rng(B + T)
+    adj_np = synth.dependency_batch(B, T, min(4.0, T), seed=3, lengths=rng.integers(1, T + 1, size=B))
+    adj = torch.from_numpy(adj_np).to(dev)
+    x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32)).to(dev)
+    g1, g2 = torch.rand(B, H, device=dev), torch.rand(B, H, device=dev)
+    (w1, b1), (w2, b2) = synth.layer_params(H, H, seed=1), synth.layer_params(H, H, seed=2)
+    l1, l2 = _layer(pkg, dev, w1, b1, "f16mx8"), _layer(pkg, dev, w2, b2, "f16mx8")
+    csr = pkg.BatchedCSR.from_dense(adj)
+    with torch.no_grad():
+        r8 = pkg.gated_gcn_block(x, csr, g1, g2, l1, l2)
+        os.environ["GGCN_BLOCK_FORM"] = "4"
+        try:
+            r4 = pkg.gated_gcn_block(x, csr, g1, g2, l1, l2)
+        finally:
+            os.environ.pop("GGCN_BLOCK_FORM", None)
+        r8b = pkg.gated_gcn_block(x, csr, g1, g2, l1, l2)
+        with_gcn1 = pkg.gated_gcn_block(x, csr, g1, g2, l1, l2, want_gcn1=True)       # (the four-wavefront kernel: gcn1 is its output)
+    for k in ("x1", "y1", "x", "out"):
+        assert torch.equal(r8[k], r4[k]) and torch.equal(r8[k], r8b[k]) and torch.equal(r8[k], with_gcn1[k]), k
+    assert float(r8["xy"]) == float(r4["xy"]) == float(r8b["xy"])
+    sl = slice(0, 40)
+    ref = _oracle_block(x[sl].cpu().numpy(), adj_np[sl], g1[sl].cpu().numpy(), g2[sl].cpu().numpy(), w1, b1, w2, b2)
+    for k in ("x1", "y1", "x", "out"):
+        np.testing.assert_allclose(r8[k][sl].cpu().numpy(), ref[k].numpy(), rtol=0, atol=TOL["f16mx8"] * max(1.0, float(ref[k].abs().max())))
 
 
 # ---------------------------------------------------------------- N > 1 product path on one device (SURVEY 8e)

@@ -50,6 +50,26 @@ if os.environ.get("LAB_ONLY") == "8":
 if os.environ.get("LAB_ONLY") == "4":
     for _ in range(int(os.environ.get("LAB_REPS", 60))): run4()
     torch.cuda.synchronize(); sys.exit(0)
+if os.environ.get("LAB_ENERGY"):   # each form ALONE for 1.5 s with the board power beside it: the kernels sit at the power cap, and
+    import time                    # five-launch interleaved timings (below) mix the two forms' power states
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for rep in range(2):
+        for name, f in (("block_fused (4 wavefronts, 2 per CU)", run4), ("lab_block_fused8 (8 wavefronts, shared X)", run8)):
+            for _ in range(300): f()
+            torch.cuda.synchronize()
+            with bench.PowerSampler() as ps:
+                a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t_end, cnt = time.perf_counter() + 1.5, 0
+                a.record()
+                while time.perf_counter() < t_end:
+                    for _ in range(100): f()
+                    cnt += 100; torch.cuda.synchronize()
+                e.record(); torch.cuda.synchronize()
+            us, pw = a.elapsed_time(e) / cnt * 1e3, ps.summary()
+            print("%-44s %.1f us  %.0f W (sclk %s MHz)  %.4f J" % (name, us, pw.get("power_w") or float("nan"), pw.get("sclk_dpm_mhz"),
+                                                                 us * 1e-6 * (pw.get("power_w") or float("nan"))), flush=True)
+    sys.exit(0)
 for _ in range(150): run4()
 times = {"block_fused (4 wavefronts, 2 per CU)": [], "lab_block_fused8 (8 wavefronts, shared X)": []}
 fns = [run4, run8]
