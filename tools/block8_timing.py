@@ -32,6 +32,12 @@ def bufs():
     return dict(xo=e(B * T, H), x1=e(B, H), y1=e(B, H), out=e(B, H), part=e(B, 12))
 r4, r8 = bufs(), bufs()
 def run4(r=r4):
+    os.environ["GGCN_BLOCK_FORM"] = "4"   # (since late round 5 ggcn_block_fused itself takes the eight-wavefront kernel from 2048 graphs up)
+    try:
+        return _run4(r)
+    finally:
+        os.environ.pop("GGCN_BLOCK_FORM", None)
+def _run4(r):
     return lib.ggcn_block_fused(P(x), H, P(pack1), P(pack12), P(ops), P(ops2), P(b1), P(mid), P(b2), B, T, H, H, P(g1), P(g2), None, H,
                                 P(r["xo"]), H, P(r["x1"]), P(r["y1"]), P(r["out"]), P(r["part"]), _capi.PREC["f16mx8"], st)
 def run8(r=r8):
