@@ -5,6 +5,12 @@ each, interleaved in ONE process (cdna guide §5.4 rule 24).  Development tool, 
   python tools/lab.py build  name1:-DFLAG_A name2:"-DFLAG_B -DFLAG_C" ...   (CPU box: cross-compiles)
   python tools/lab.py build  old@<git-rev>[:flags]                            (the csrc/ of that revision)
   python tools/lab.py time linear|aggregate|block [names...]                 (GPU box)
+
+LAB_ENERGY=1 times every variant ALONE for 1.5 s with the board power beside it.  For kernels at the board's power cap (the block
+kernel, config 4, dW) that is the yardstick for variants with a DIFFERENT power profile: the power controller averages over
+milliseconds, so in a five-launch interleave the cheaper variant runs at the clock the dearer one leaves it -- the eight-wavefront
+block kernel read 1-6 % slower interleaved and is 2-4 % faster in steady state.  Small variants of one loop
+compare fine either way.
 """
 import ctypes
 import os
