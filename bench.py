@@ -888,7 +888,7 @@ def main():
         t = statistics.mean(kern_us["ggcn_block_fused"])
         # (ggcn_block_fused runs batches of >= 2048 graphs on the eight-wavefront workgroup that stages a row block's X planes once
         # for a W1 and a W12 column slice -- fused_block8.hip; GGCN_BLOCK_FORM=4 keeps the four-wavefront kernel)
-        form8 = (args.precision == "f16mx8" and B >= 2048 and H % 256 == 0 and os.environ.get("GGCN_BLOCK_FORM", "8")[:1] != "4")
+        form8 = args.precision == "f16mx8" and lib.ggcn_block_fused_form(B, T, H, H) == 8
         roofline = mfma_line("block_fused8_kernel (both layers of the block in one launch; eight wavefronts share a row block's X planes)" if form8 else
                              "layer_fused_kernel (block form: both layers of the block in one launch)",
                              ("block_fused8_kernel:" if form8 else "block_fused_kernel:") + args.precision, t, 2 * (lin_flops + agg_flops), fwd_bytes,

@@ -83,6 +83,7 @@ PROTOTYPES = {
                                  c_vp, c_i64, c_vp, c_vp, c_vp]),
     "ggcn_layer_fused_h": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                    c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "ggcn_block_fused_form": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "ggcn_dense_head": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
     "ggcn_dense_head_signal": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "ggcn_overlap_workspace_bytes": (c_sz, [c_i32]),

@@ -257,6 +257,12 @@ int ggcn_gate_pool_backward_agg(const float *out, int64_t ldo, const float *stor
                                   d_ga, d_gb, d_bsum, as_stream(stream), p > 0.0f ? &d : nullptr, dh_amax);
 }
 
+int ggcn_block_fused_form(int B, int T, int K, int F)
+{
+    const char *form = getenv("GGCN_BLOCK_FORM");
+    return (block8_shape(B, T, K, F) && !(form && form[0] == '4')) ? 8 : 4;
+}
+
 int ggcn_lab_block_fused8(const float *X, int64_t ldx, const void *wpack1, const void *wpack12, const void *graph_ops,
                           const void *graph_ops2, const float *bias1, const float *bias_mid, const float *bias2, int B, int T, int K, int F,
                           const float *gate1, const float *gate2, float *x_out, int64_t ld2, float *x1, float *y1, float *pool_out,

@@ -136,6 +136,7 @@ int lab_block_fused8(const float *X, int64_t ldx, const void *wpack1, const void
                      const float *gate2, float *x_out, int64_t ld2, float *x1, float *y1, float *pool_out, float *overlap_partial,
                      hipStream_t st, unsigned long long *stamps = nullptr, int flags = 0);
 constexpr int kBlock8RowMajor = 1, kBlock8NoDma = 2, kBlock8SameSlots = 4, kBlock8Product = 8;
+bool block8_shape(int B, int T, int K, int F);
 bool block8_takes(const float *X, int64_t ldx, int B, int T, int K, int F, const float *gate1, const float *gate2, const float *bias1,
                   const float *bias_mid, const float *bias2, const void *graph_ops, const void *graph_ops2, const float *x_out, int64_t ld2);
 int range_flag_fused6(unsigned int *dst, int clear, hipStream_t st);   // fused6.hip (GGCN_WITH_F16MX6)

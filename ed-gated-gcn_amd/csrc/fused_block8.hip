@@ -104,17 +104,35 @@ __global__ __launch_bounds__(kB8Threads, 1) void block_fused8_kernel(const Fused
 
 }  // namespace
 
-// What ggcn_block_fused hands to this kernel (fused_layer.hip): the whole block with all of its outputs, f16mx8, on batches of at
-// least kBlock8MinGraphs graphs -- 6 and more rounds of one eight-wavefront workgroup per CU.  There, with the board at its power
+// What ggcn_block_fused hands to this kernel (fused_layer.hip): the whole block with all of its outputs, f16mx8, on batches that
+// make 6 and more rounds of one eight-wavefront workgroup per CU (or 3 and more whole rounds).  There, with the board at its power
 // cap, the X planes staged once for a W1 and a W12 column slice are worth 2 % of the launch IN STEADY STATE (each form alone for
 // 1.5 s: 603-604 vs 615-618 us at 4096 graphs on two boxes, 639 vs 653 on a slower one, 304-309 vs 313 at 2048; 512 graphs: 85 vs
 // 80 us, so shards keep the four-wavefront kernel) -- while five-launch interleaved timings had shown it 3-6 % SLOWER:
 // the power controller averages over milliseconds, and the benchmark's timed region is a steady state.
-constexpr int kBlock8MinGraphs = 2048;
+// One eight-wavefront workgroup per CU: a partial last round costs a whole one (1536 graphs = 4.5 rounds: 243 vs 237 us), so the
+// kernel is taken from 6 rounds up (2048 graphs x 768 columns) or for 3 and more WHOLE rounds (1024 graphs: 149.5 vs 152-153 us).
+int device_cu_count()
+{
+    static int cus = 0;   // (one device kind per process: MI355X, 256)
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+// the shape's share of the rule (ggcn_block_fused_form: what bench.py labels its roofline line with, what the tests ask)
+bool block8_shape(int B, int T, int K, int F)
+{
+    if (B <= 0 || T > 32 || T <= 0 || F <= 0 || K <= 0 || F % BN != 0 || K % BK != 0) return false;
+    const int64_t total = (int64_t)((B + 3) / 4) * (F / BN), cus = device_cu_count();
+    return total >= 6 * cus || (total >= 3 * cus && total % cus == 0);
+}
 bool block8_takes(const float *X, int64_t ldx, int B, int T, int K, int F, const float *gate1, const float *gate2, const float *bias1,
                   const float *bias_mid, const float *bias2, const void *graph_ops, const void *graph_ops2, const float *x_out, int64_t ld2)
 {
-    if (B < kBlock8MinGraphs || T > 32 || T <= 0 || F % BN != 0 || K % BK != 0) return false;
+    if (!block8_shape(B, T, K, F)) return false;
     if (!((ldx % 4 == 0) && aligned16(X) && (int64_t)ldx * 4 * 257 < ((int64_t)1 << 31))) return false;
     if (!graph_ops || !graph_ops2 || !gate1 || !gate2 || !bias_mid) return false;
     if (!(aligned16(gate1) && aligned16(gate2) && aligned16(bias1) && aligned16(bias2) && aligned16(bias_mid) && aligned16(graph_ops) &&

@@ -498,6 +498,13 @@ int ggcn_debug_poison_lds(uint32_t pattern, ggcn_stream_t stream);
  * uint64[2 * workgroups], workgroups = ceil(B/16) * ceil(F/256) * 8): same results, a few percent slower; no product launch
  * executes a stamp. */
 int ggcn_debug_mfma_calibrate(int n_wg, int stages, uint64_t *stamps, float *sink, ggcn_stream_t stream);
+/* Which kernel ggcn_block_fused takes for the whole block (all outputs, GGCN_PREC_F16MX8, 16-byte aligned operands) at this shape:
+ * 8 = one eight-wavefront workgroup per (row block, 256-column slice) that stages the row block's X planes once for its W1 and its
+ * W12 tiles (fused_block8.hip) -- batches that make >= 6 rounds of one workgroup per CU, or >= 3 whole rounds; 2-4 % less time in
+ * steady state at the board's power cap, the same bits -- else 4 = two four-wavefront workgroups per CU (fused_layer.hip).
+ * GGCN_BLOCK_FORM=4 in the environment (read per call) keeps the four-wavefront kernel. */
+int ggcn_block_fused_form(int B, int T, int K, int F);
+
 /* EXPERIMENT, called by nothing in the product (tools/block8_timing.py, one parity test): ggcn_block_fused's tiles in workgroups of
  * EIGHT wavefronts that share a row block's X planes between the W1 and the W12 column tiles of a 256-column slice (f16mx8, T <= 32,
  * K % 32 == 0, 16-byte rows, no gcn1).  Bit-identical results; measured slower. */

@@ -1751,7 +1751,7 @@ def test_precomputed_edge_lists_of_the_eight_wavefront_layer(pkg, dev, B, T, F):
 @pytest.mark.parametrize("B,T,H", [(16, 32, 256), (37, 23, 256), (5, 32, 768), (3, 7, 64)])
 def test_eight_wavefront_shared_x_experiment_is_bit_identical_to_the_block(pkg, dev, B, T, H):
     """ggcn_lab_block_fused8 (one workgroup of eight wavefronts shares a row block's X planes between its W1
-    and W12 column tiles; since late round 5 also what ggcn_block_fused runs for batches of >= 2048 graphs): the same tiles, arithmetic and order as the four-wavefront kernel,
+    and W12 column tiles; since late round 5 also what ggcn_block_fused runs for large batches): the same tiles, arithmetic and order as the four-wavefront kernel,
     so x, x1, y1, out and the regulariser's partials are the same bits -- whole and ragged batches, both XCD mappings, with and
     without the [N,F] output."""
     from ed_gated_gcn_amd import _capi, synth
@@ -1794,11 +1794,11 @@ def test_eight_wavefront_shared_x_experiment_is_bit_identical_to_the_block(pkg, 
             os.environ.pop("GGCN_LAB_BLOCK8_ROWMAJOR", None)
 
 
-@pytest.mark.parametrize("B,T,H", [(2048, 32, 256), (2100, 29, 256)])
+@pytest.mark.parametrize("B,T,H", [(2048, 32, 768), (2100, 29, 768), (1024, 32, 768)])
 def test_large_batches_take_the_eight_wavefront_block_and_nothing_changes(pkg, dev, B, T, H):
-    """ggcn_block_fused hands batches of >= 2048 graphs (all outputs, f16mx8, whole 256-column groups) to the eight-wavefront
-    kernel of fused_block8.hip (2 % less time in steady state at the power cap); GGCN_BLOCK_FORM=4 keeps the four-wavefront
-    kernel.  Same tiles, same arithmetic, same order: every output the same bits, whole and ragged batches; against the oracle on
+    """ggcn_block_fused hands batches that make >= 6 rounds of one workgroup per CU (or >= 3 whole rounds: 1024 x 768) -- all
+    outputs, f16mx8, whole 256-column groups -- to the eight-wavefront kernel of fused_block8.hip (2-4 % less time in steady state
+    at the power cap); GGCN_BLOCK_FORM=4 keeps the four-wavefront kernel (ggcn_block_fused_form says which).  Same tiles, same arithmetic, same order: every output the same bits, whole and ragged batches; against the oracle on
     a slice; smaller batches, the eval form and a request for gcn1 stay where they were."""
     from ed_gated_gcn_amd import synth
     rng = np.random.default_rng(B + T)
@@ -1809,10 +1809,14 @@ def test_large_batches_take_the_eight_wavefront_block_and_nothing_changes(pkg, d
     (w1, b1), (w2, b2) = synth.layer_params(H, H, seed=1), synth.layer_params(H, H, seed=2)
     l1, l2 = _layer(pkg, dev, w1, b1, "f16mx8"), _layer(pkg, dev, w2, b2, "f16mx8")
     csr = pkg.BatchedCSR.from_dense(adj)
+    lib = pkg.load_library()
+    assert lib.ggcn_block_fused_form(B, T, H, H) == 8 and lib.ggcn_block_fused_form(512, T, H, H) == 4
+    assert lib.ggcn_block_fused_form(1536, 32, 768, 768) == 4 and lib.ggcn_block_fused_form(B, T, H, 200) == 4     # 4.5 rounds; no whole slices
     with torch.no_grad():
         r8 = pkg.gated_gcn_block(x, csr, g1, g2, l1, l2)
         os.environ["GGCN_BLOCK_FORM"] = "4"
         try:
+            assert lib.ggcn_block_fused_form(B, T, H, H) == 4
             r4 = pkg.gated_gcn_block(x, csr, g1, g2, l1, l2)
         finally:
             os.environ.pop("GGCN_BLOCK_FORM", None)
